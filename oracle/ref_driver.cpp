@@ -1,0 +1,341 @@
+/*
+ * oracle/ref_driver.cpp -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * Thin driver that links the *real* MASA-Core objects compiled from
+ * /root/reference (see oracle/build_ref.sh) and runs the reference's own
+ * stage1()..stage6() on a FASTA pair.  It exists only to pin oracle/sw_oracle.c
+ * and the HIP engine against the reference's own CPU path and to generate the
+ * fixtures under tests/golden/.
+ *
+ * Two reference files on this path cannot be compiled in this image because
+ * they include autoconf/awk generated headers (config.h / default.h):
+ *   libs/masa-core/src/libmasa/libmasa.cpp            (CLI, getopt table)
+ *   libs/masa-core/src/libmasa/aligners/AbstractBlockAligner.cpp
+ * (and AbstractDiagonalAligner.*, configs/Configs.cpp which nothing here uses).
+ * Everything else (82 sources: CPUBlockProcessor, Grid, pruning/*, AlignerManager,
+ * BestScoreList, sra/*, io/*, stage1..6, Job ...) is the unmodified reference.
+ *
+ * What this file re-states (my code, following the cited reference lines):
+ *   - SerialBlockAligner: the block schedule of AbstractBlockAligner
+ *     (AbstractBlockAligner.cpp:276-327 alignPartition, :362-392 processBlock,
+ *      :418-449 isSpecialRow/isSpecialColumn, :141-167 capabilities) with the serial
+ *      scheduler of SURVEY.md section 8c.  The cell arithmetic is NOT restated here: it is the
+ *      reference's CPUBlockProcessor::processBlock, the pruning is the reference's
+ *      BlockPruningGenericN2, the manager is the reference's AlignerManager.
+ *   - main(): the part of libmasa_entry_point (libmasa.cpp:762-1400) that builds
+ *     the Job and calls the stages, with a minimal flag parser.
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <string>
+#include <vector>
+#include <algorithm>
+
+#include "libmasa/libmasa.hpp"
+#include "libmasa/aligners/AbstractAligner.hpp"
+#include "libmasa/processors/CPUBlockProcessor.hpp"
+#include "libmasa/pruning/BlockPruningGenericN2.hpp"
+#include "libmasa/parameters/BlockAlignerParameters.hpp"
+#include "common/Common.hpp"
+#include "common/Job.hpp"
+
+int stage1(Job* job);
+crosspoint_t stage2(Job* job, int id);
+int stage3(Job* job, int id);
+int stage4(Job* job, int id);
+int stage5(Job* job, int id);
+int stage6(Job* job, int id);
+
+/* Same constants as AbstractBlockAligner.cpp:41-45 / CUDAligner.hpp:77-98 */
+#define REF_MATCH     (1)
+#define REF_MISMATCH  (-3)
+#define REF_GAP_EXT   (2)
+#define REF_GAP_OPEN  (3)
+
+class SerialBlockAligner : public AbstractAligner {
+public:
+    SerialBlockAligner(int bh, int bw) : blockH(bh), blockW(bw), row(NULL), col(NULL),
+            totalBlocks(0), prunedBlocks(0) {
+        score_params.match = REF_MATCH;
+        score_params.mismatch = REF_MISMATCH;
+        score_params.gap_open = REF_GAP_OPEN;
+        score_params.gap_ext = REF_GAP_EXT;
+        params = new BlockAlignerParameters();
+        processor = new CPUBlockProcessor();
+        pruner = new BlockPruningGenericN2();
+        setForkCount(1);
+    }
+    virtual ~SerialBlockAligner() {}
+
+    /* AbstractBlockAligner.cpp:141-167 */
+    virtual aligner_capabilities_t getCapabilities() {
+        aligner_capabilities_t c;
+        c.smith_waterman = SUPPORTED;
+        c.needleman_wunsch = SUPPORTED;
+        c.block_pruning = SUPPORTED;
+        c.customize_first_column = SUPPORTED;
+        c.customize_first_row = SUPPORTED;
+        c.dispatch_last_cell = NOT_SUPPORTED;
+        c.dispatch_last_column = SUPPORTED;
+        c.dispatch_last_row = SUPPORTED;
+        c.dispatch_special_column = SUPPORTED;
+        c.dispatch_special_row = SUPPORTED;
+        c.dispatch_block_scores = SUPPORTED;
+        c.dispatch_scores = SUPPORTED;
+        c.process_partition = SUPPORTED;
+        c.variable_penalties = NOT_SUPPORTED;
+        c.fork_processes = SUPPORTED;
+        c.maximum_seq0_len = 0;
+        c.maximum_seq1_len = 0;
+        return c;
+    }
+    virtual const score_params_t* getScoreParameters() { return &score_params; }
+    virtual IAlignerParameters* getParameters() { return params; }
+    virtual void initialize() {}
+    virtual void finalize() {}
+    virtual void setSequences(const char* s0, const char* s1, int l0, int l1) {
+        processor->setSequences(s0, s1, l0, l1);
+    }
+    virtual void unsetSequences() { processor->unsetSequences(); }
+    virtual void clearStatistics() { totalBlocks = prunedBlocks = 0; }
+    virtual void printInitialStatistics(FILE*) {}
+    virtual void printStageStatistics(FILE*) {}
+    virtual void printFinalStatistics(FILE*) {}
+    virtual void printStatistics(FILE* f) {
+        fprintf(f, "Pruned Blocks: %d / %d\n", prunedBlocks, totalBlocks);
+    }
+    virtual const char* getProgressString() const { return ""; }
+    virtual long long getProcessedCells() { return 0; }
+
+    /* AbstractBlockAligner.cpp:276-327 with the serial schedule of SURVEY.md 8c */
+    virtual void alignPartition(Partition partition) {
+        Grid* grid = createGrid(partition);
+        grid->setBlockHeight(blockH);
+        grid->setBlockWidth(blockW);
+        initializeBlockPruning(pruner);
+
+        const int gw = grid->getGridWidth();
+        const int gh = grid->getGridHeight();
+        row = new cell_t*[gw];
+        for (int j = 0; j < gw; j++) row[j] = new cell_t[grid->getBlockWidth(j, 0)];
+        col = new cell_t*[gh];
+        for (int i = 0; i < gh; i++) col[i] = new cell_t[grid->getBlockHeight(0, i) + 1];
+        std::vector<std::vector<score_t> > scores(gw, std::vector<score_t>(gh));
+        for (int bx = 0; bx < gw; bx++) for (int by = 0; by < gh; by++) {
+            scores[bx][by].i = -1; scores[bx][by].j = -1; scores[bx][by].score = -INF;
+        }
+
+        cell_t dummy;
+        receiveFirstColumn(&dummy, 1);
+        receiveFirstRow(&dummy, 1);
+
+        for (int by = 0; by < gh; by++) {
+            for (int bx = 0; bx < gw; bx++) {
+                int i0, j0, i1, j1;
+                grid->getBlockPosition(bx, by, &i0, &j0, &i1, &j1);
+                if (by == 0) receiveFirstRow(row[bx], j1 - j0);
+                if (bx == 0) {
+                    col[by][0] = getFirstColumnTail();
+                    receiveFirstColumn(col[by] + 1, i1 - i0);
+                }
+                if (bx == 0 && isSpecialRow(by)) {
+                    cell_t c = col[by][i1 - i0]; c.f = -INF; dispatchRow(i1, &c, 1);
+                }
+                if (by == 0 && isSpecialColumn(bx)) {
+                    cell_t c = row[bx][j1 - j0 - 1]; c.f = -INF; dispatchColumn(j1, &c, 1);
+                }
+                /* AbstractBlockAligner.cpp:362-392 */
+                totalBlocks++;
+                if (!pruner->isBlockPruned(bx, by)) {
+                    scores[bx][by] = processor->processBlock(row[bx], col[by], i0, j0, i1, j1,
+                            getRecurrenceType());
+                    pruner->pruningUpdate(bx, by, scores[bx][by].score);
+                } else {
+                    prunedBlocks++;
+                }
+                if (isSpecialRow(by)) dispatchRow(i1, row[bx], j1 - j0);
+                if (isSpecialColumn(bx)) dispatchColumn(j1, col[by] + 1, i1 - i0);
+            }
+        }
+        /* AbstractBlockAligner.cpp:310-315 */
+        for (int bx = 0; bx < gw; bx++)
+            for (int by = 0; by < gh; by++)
+                dispatchScore(scores[bx][by], bx, by);
+        /* AbstractBlockAligner.cpp:317-323 */
+        if (mustDispatchLastCell()) {
+            score_t s;
+            s.score = row[gw - 1][grid->getBlockWidth(gw - 1, gh - 1) - 1].h;
+            s.i = partition.getI1() - 1;
+            s.j = partition.getJ1() - 1;
+            dispatchScore(s, gw - 1, gh - 1);
+        }
+        for (int j = 0; j < gw; j++) delete[] row[j];
+        delete[] row;
+        for (int i = 0; i < gh; i++) delete[] col[i];
+        delete[] col;
+    }
+
+private:
+    /* AbstractBlockAligner.cpp:418-439 */
+    bool isSpecialRow(int by) {
+        if (mustDispatchLastRow() && by == getGrid()->getGridHeight() - 1) return true;
+        if (mustDispatchSpecialRows()) {
+            const int bh = getGrid()->getBlockHeight(0, 0);
+            int interval = (getSpecialRowInterval() + bh - 1) / bh;
+            if (interval <= 0) interval = 1;
+            return ((by + 1) % interval == 0);
+        }
+        return false;
+    }
+    /* AbstractBlockAligner.cpp:447-449 */
+    bool isSpecialColumn(int bx) {
+        return mustDispatchLastColumn() && bx == getGrid()->getGridWidth() - 1;
+    }
+
+    int blockH, blockW;
+    cell_t** row;
+    cell_t** col;
+    score_params_t score_params;
+    BlockAlignerParameters* params;
+    CPUBlockProcessor* processor;
+    BlockPruningGenericN2* pruner;
+    int totalBlocks, prunedBlocks;
+};
+
+static int parse_edge(char c) {
+    switch (c) {
+    case '*': return AT_ANYWHERE;
+    case '1': return AT_SEQUENCE_1;
+    case '2': return AT_SEQUENCE_2;
+    case '3': return AT_SEQUENCE_1_OR_2;
+    case '+': return AT_SEQUENCE_1_AND_2;
+    }
+    fprintf(stderr, "bad edge flag %c\n", c);
+    exit(2);
+}
+
+static long long parse_size(const char* s) {
+    char* end;
+    double v = strtod(s, &end);
+    if (*end == 'K') v *= 1024.0;
+    else if (*end == 'M') v *= 1024.0 * 1024.0;
+    else if (*end == 'G') v *= 1024.0 * 1024.0 * 1024.0;
+    return (long long) v;
+}
+
+/*
+ * usage: ref_driver [options] seq0.fasta seq1.fasta
+ *   --work-dir=DIR --stage-1 --edges=XY --disk-size=N[KMG] --no-flush
+ *   --no-block-pruning --block=H,W --split=COUNT --part=STEP
+ *   --flush-column=URL --load-column=URL --max-alignments=N
+ */
+int main(int argc, char** argv) {
+    std::string work = "./work.tmp";
+    bool stage1_only = false;
+    int astart = AT_ANYWHERE, aend = AT_ANYWHERE;
+    long long disk = 0, ram = 0;
+    bool pruning = true;
+    int bh = 1024, bw = 1024;
+    int split_count = 0, split_step = 0;
+    int max_alignments = 1;
+    std::string flush_url, load_url;
+    std::vector<const char*> files;
+
+    for (int a = 1; a < argc; a++) {
+        const char* s = argv[a];
+        if (!strncmp(s, "--work-dir=", 11)) work = s + 11;
+        else if (!strcmp(s, "--stage-1")) stage1_only = true;
+        else if (!strncmp(s, "--edges=", 8)) { astart = parse_edge(s[8]); aend = parse_edge(s[9]); }
+        else if (!strncmp(s, "--disk-size=", 12)) { if (disk != -1) disk = parse_size(s + 12); }
+        else if (!strncmp(s, "--ram-size=", 11)) { if (ram != -1) ram = parse_size(s + 11); }
+        else if (!strcmp(s, "--no-flush")) { disk = -1; ram = -1; }
+        else if (!strcmp(s, "--no-block-pruning")) pruning = false;
+        else if (!strncmp(s, "--block=", 8)) sscanf(s + 8, "%d,%d", &bh, &bw);
+        else if (!strncmp(s, "--split=", 8)) split_count = atoi(s + 8);
+        else if (!strncmp(s, "--part=", 7)) split_step = atoi(s + 7);
+        else if (!strncmp(s, "--flush-column=", 15)) { flush_url = s + 15; pruning = false; }
+        else if (!strncmp(s, "--load-column=", 14)) { load_url = s + 14; pruning = false; }
+        else if (!strncmp(s, "--max-alignments=", 17)) max_alignments = atoi(s + 17);
+        else if (s[0] == '-') { fprintf(stderr, "unknown option %s\n", s); return 2; }
+        else files.push_back(s);
+    }
+    if (files.size() != 2) { fprintf(stderr, "need two fasta files\n"); return 2; }
+
+    SerialBlockAligner* aligner = new SerialBlockAligner(bh, bw);
+
+    /* libmasa.cpp:765-806 defaults */
+    Job* job = new Job(2);
+    job->configs = NULL;
+    AlignmentParams* ap = job->getAlignmentParams();
+    ap->setAlignmentMethod(ALIGNMENT_METHOD_LOCAL);
+    const score_params_t* sp = aligner->getScoreParameters();
+    ap->setAffineGapPenalties(-sp->gap_open, -sp->gap_ext);
+    ap->setMatchMismatchScores(sp->match, sp->mismatch);
+    job->disk_limit = disk;
+    job->ram_limit = ram;
+    job->block_pruning = pruning;
+    job->dump_blocks = false;
+    job->setWorkPath(work);
+    job->stage4_maximum_partition_size = 16;
+    job->stage4_strategy = STAGE_4_STRATEGY_OPTIMIZED;
+    job->stage6_output_format = 0;
+    job->flush_column_url = flush_url;
+    job->load_column_url = load_url;
+    job->alignment_start = astart;
+    job->alignment_end = aend;
+    job->max_alignments = max_alignments;
+    job->peer_listen_port = -1;
+    job->predicted_traceback = false;
+    job->setBufferLimit(1024 * 1024);
+    job->aligner = aligner;
+
+    /* libmasa.cpp:1269-1288 */
+    for (int i = 0; i < 2; i++) {
+        SequenceInfo* info = new SequenceInfo();
+        info->setFilename(files[i]);
+        SequenceModifiers* mod = new SequenceModifiers();
+        mod->setClearN(false);
+        mod->setReverse(false);
+        mod->setComplement(false);
+        mod->setTrimStart(0);
+        mod->setTrimEnd(0);
+        Sequence* seq = new Sequence(info, mod);
+        job->addSequence(seq);
+        ap->addSequence(seq);
+    }
+
+    /* libmasa.cpp:497-535 split_sequences with equal weights */
+    if (split_count > 0) {
+        int seq1_len = ap->getSequence(1)->getLen();
+        int trim_j0 = (int) ((((long long) seq1_len) * (split_step - 1)) / split_count + 1);
+        int trim_j1 = (int) ((((long long) seq1_len) * split_step) / split_count);
+        char str[256];
+        if (split_step > 1 && job->load_column_url == "") {
+            sprintf(str, "file://%s/../STEP-%d-%d-%d.tmp", work.c_str(), split_step - 1, split_count, trim_j0 - 1);
+            job->load_column_url = str;
+        }
+        if (split_step < split_count && job->flush_column_url == "") {
+            sprintf(str, "file://%s/../STEP-%d-%d-%d.tmp", work.c_str(), split_step, split_count, trim_j1);
+            job->flush_column_url = str;
+        }
+        ap->getSequence(1)->trim(trim_j0, trim_j1);
+        job->block_pruning = false;
+    }
+
+    if (!job->initialize()) { fprintf(stderr, "job init failed\n"); return 1; }
+
+    /* libmasa.cpp:1349-1385 */
+    int count = stage1(job);
+    if (!stage1_only) {
+        for (int id = 0; id < count; id++) {
+            stage2(job, id);
+            stage3(job, id);
+            stage4(job, id);
+            stage5(job, id);
+            stage6(job, id);
+        }
+    }
+    aligner->finalize();
+    return 0;
+}
