@@ -1,0 +1,204 @@
+/*
+ * mi355sw.h -- C ABI of the MI355X-native Stage-1 SW/NW strip-wavefront engine.
+ *
+ * This is the drop-in boundary for the Stage-1 hot path of MASA-CUDAlign.  Every entry point
+ * cites the reference interface it replaces ("M/" = masa-cudalign-4.0.2.1028/libs/masa-core/src/,
+ * "X/" = masa-cudalign-4.0.2.1028/src/).  Plain C types only: no C++, no torch, no HIP types.
+ * All functions return 0 on success or a negative MI355SW_E* code (never exit(); the reference's
+ * cutilSafeCall aborts, X/cuda_util.h:34-42); mi355sw_last_error() gives the message.
+ *
+ * Threading: like MASA-Core (M/libmasa/IAligner.hpp:55-100) one thread drives a handle; manager
+ * callbacks are invoked only from the thread that called mi355sw_align_partition().
+ * mi355sw_progress() may be called from another thread (logger pthread, sw_stage1.cpp:113-128).
+ */
+#ifndef MI355SW_H_
+#define MI355SW_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI355SW_ABI_VERSION 1
+
+/* M/libmasa/libmasaTypes.hpp:35-41  cell_t {int h; union{int f; int e;};} 8-byte aligned */
+typedef struct { int32_t h; int32_t f; } mi355sw_cell;
+/* M/libmasa/libmasaTypes.hpp:88-95  score_t */
+typedef struct { int32_t i; int32_t j; int32_t score; } mi355sw_score;
+/* M/libmasa/libmasaTypes.hpp:100-109 score_params_t */
+typedef struct { int32_t match, mismatch, gap_open, gap_ext; } mi355sw_score_params;
+/* M/libmasa/libmasaTypes.hpp:51-60 match_result_t */
+typedef struct { int32_t found, k, score, type; } mi355sw_match_result;
+/* M/libmasa/Partition.hpp: half-open [i0,i1) x [j0,j1) in sequence-relative coordinates */
+typedef struct { int32_t i0, j0, i1, j1; } mi355sw_partition;
+
+#define MI355SW_INF 999999999                 /* libmasaTypes.hpp:46 */
+#define MI355SW_NEEDLEMAN_WUNSCH 0            /* IManager.hpp:31 */
+#define MI355SW_SMITH_WATERMAN 1              /* IManager.hpp:33 */
+#define MI355SW_INIT_WITH_ZEROES 0            /* IManager.hpp:38 */
+#define MI355SW_INIT_WITH_GAPS 1              /* IManager.hpp:41 */
+#define MI355SW_INIT_WITH_CUSTOM_DATA 2       /* IManager.hpp:47 */
+#define MI355SW_INIT_WITH_GAPS_OPENED 3       /* IManager.hpp:44 */
+
+#define MI355SW_OK 0
+#define MI355SW_EINVAL (-1)     /* bad argument / call order                    */
+#define MI355SW_EHIP (-2)       /* HIP runtime error                            */
+#define MI355SW_ENOGPU (-3)     /* no usable gfx950 device                      */
+#define MI355SW_ENOMEM (-4)
+#define MI355SW_ETIMEOUT (-5)   /* a bounded in-kernel spin gave up             */
+#define MI355SW_ESTATE (-6)
+
+typedef struct mi355sw_handle mi355sw_handle;
+
+/* Extension parameters; replaces X/CUDAlignerParameters.cpp:33-110 (--gpu, --blocks). */
+typedef struct {
+    int32_t device;          /* HIP ordinal, -1 = current device (reference: --gpu)                 */
+    int32_t rows_per_lane;   /* R in {4,8,16}; strip height = 64*R (reference: THREADS_COUNT*ALPHA);
+                                0 = choose from the partition size                                 */
+    int32_t waves;           /* persistent wavefronts (reference: --blocks); 0 = auto              */
+    int32_t flags;           /* MI355SW_F_*                                                          */
+    int64_t max_special_bytes; /* HBM budget for device-resident special rows, 0 = default (8 GiB) */
+} mi355sw_config;
+#define MI355SW_F_FORCE_GENERIC_COMPARE 1   /* raw byte compare kernels even if a profile fits */
+
+/* aligner_capabilities_t, M/libmasa/capabilities.hpp:59-225 (same fields, int32 instead of bool) */
+typedef struct {
+    int32_t dispatch_last_cell, dispatch_last_row, dispatch_last_column;
+    int32_t dispatch_special_row, dispatch_special_column;
+    int32_t dispatch_scores, dispatch_block_scores, dispatch_best_score;
+    int32_t customize_first_row, customize_first_column;
+    int32_t process_partition, variable_penalties, block_pruning;
+    int32_t needleman_wunsch, smith_waterman, fork_processes;
+    int32_t maximum_seq0_len, maximum_seq1_len;
+} mi355sw_capabilities;
+
+/* The IManager callbacks the aligner drives, M/libmasa/IManager.hpp:98-313, as C function
+ * pointers.  `user` is passed back verbatim.  Semantics as in the reference:
+ *  - receive_first_row/column are sequential streams; the first call consumes the corner cell
+ *    (M/libmasa/aligners/AbstractDiagonalAligner.cpp:84-86);
+ *  - dispatch_row(i,...)/dispatch_column(j,...) are called in increasing position per row/column,
+ *    the first call of a row/column carries the border cell with f = -INF
+ *    (AbstractDiagonalAligner.cpp:290-298, :419-422); buffers are borrowed for the call;
+ *  - must_continue()==0 makes mi355sw_align_partition return promptly. */
+typedef struct {
+    int32_t (*get_recurrence_type)(void* user);
+    int32_t (*get_special_row_interval)(void* user);
+    int32_t (*get_first_column_init_type)(void* user);
+    int32_t (*get_first_row_init_type)(void* user);
+    void (*get_super_partition)(void* user, mi355sw_partition* out);
+    void (*receive_first_row)(void* user, mi355sw_cell* buffer, int32_t len);
+    void (*receive_first_column)(void* user, mi355sw_cell* buffer, int32_t len);
+    void (*dispatch_column)(void* user, int32_t j, const mi355sw_cell* buffer, int32_t len);
+    void (*dispatch_row)(void* user, int32_t i, const mi355sw_cell* buffer, int32_t len);
+    void (*dispatch_score)(void* user, mi355sw_score score, int32_t bx, int32_t by);
+    int32_t (*must_continue)(void* user);
+    int32_t (*must_dispatch_last_cell)(void* user);
+    int32_t (*must_dispatch_last_row)(void* user);
+    int32_t (*must_dispatch_last_column)(void* user);
+    int32_t (*must_dispatch_special_rows)(void* user);
+    int32_t (*must_dispatch_scores)(void* user);
+    int32_t (*must_prune_blocks)(void* user);
+} mi355sw_manager;
+
+/* Timing / accounting of the last mi355sw_align_partition (reference: Timer events + MCUPS line,
+ * M/stage1/sw_stage1.cpp:440-448; getProcessedCells IAligner.hpp:377). */
+typedef struct {
+    int64_t cells;              /* m*n of the partition (GCUPS convention counts pruned cells)   */
+    int64_t processed_cells;    /* cells actually computed                                       */
+    double kernel_ms;           /* HIP-event time of the strip kernel launches on the engine's stream */
+    double total_ms;            /* wall time of the call                                         */
+    int32_t kernel_launches;
+    int32_t strips, strip_rows, waves;
+    int32_t profile_kernel;     /* 1 = 4-bit profile scoring, 0 = generic byte compare           */
+    int64_t algorithmic_bytes;  /* 17*n*ceil(m/S) + m + 8(n+1)*rows_flushed           */
+} mi355sw_stats;
+
+/* ---- life cycle: IAligner::initialize/finalize (IAligner.hpp:186,226; X/CUDAligner.cpp:137-174) ---- */
+int mi355sw_create(const mi355sw_config* config, mi355sw_handle** out);
+void mi355sw_destroy(mi355sw_handle* h);
+const char* mi355sw_last_error(mi355sw_handle* h);
+int mi355sw_abi_version(void);
+
+/* IAligner::getCapabilities (IAligner.hpp:159; X/CUDAligner.cpp:87-111) */
+int mi355sw_get_capabilities(mi355sw_handle* h, mi355sw_capabilities* out);
+/* IAligner::getScoreParameters (IAligner.hpp:177; X/CUDAligner.cpp:56-59): +1/-3/-3/-2 */
+int mi355sw_get_score_parameters(mi355sw_handle* h, mi355sw_score_params* out);
+
+/* IAligner::setSequences / unsetSequences (IAligner.hpp:197,204; X/CUDAligner.cpp:229-288).
+ * Bytes are compared raw (upper-cased FASTA bytes, X/CUDAligner.cu:276-289); the sequences are
+ * copied to HBM, the caller keeps ownership of its buffers. */
+int mi355sw_set_sequences(mi355sw_handle* h, const char* seq0, const char* seq1, int32_t seq0_len, int32_t seq1_len);
+int mi355sw_unset_sequences(mi355sw_handle* h);
+
+/* IAligner::alignPartition (IAligner.hpp:216; AbstractDiagonalAligner.cpp:59-70) */
+int mi355sw_align_partition(mi355sw_handle* h, const mi355sw_partition* partition,
+                            const mi355sw_manager* manager, void* user);
+
+/* AbstractBlockProcessor::processBlock (M/libmasa/processors/AbstractBlockProcessor.hpp:27-37,
+ * semantics CPUBlockProcessor.cpp:95-112): row[k] = (H,F) of (i0-1,j0+k) in/out, col[0] = diagonal
+ * H, col[k+1] = (H,E) of (i0+k,j0-1) in/out; returns the first strict maximum in row-major order. */
+int mi355sw_process_block(mi355sw_handle* h, mi355sw_cell* row, mi355sw_cell* col,
+                          int32_t i0, int32_t j0, int32_t i1, int32_t j1, int32_t recurrence_type,
+                          mi355sw_score* best);
+
+/* IAligner::matchLastColumn (IAligner.hpp:249; AlignerUtils::matchColumn, AlignerUtils.cpp:50-107) */
+int mi355sw_match_last_column(mi355sw_handle* h, const mi355sw_cell* buffer, const mi355sw_cell* base,
+                              int32_t len, int32_t goal_score, mi355sw_match_result* out);
+
+/* IAligner::getProgressString (IAligner.hpp:366) -- async-safe */
+int mi355sw_progress(mi355sw_handle* h, char* buf, size_t len);
+/* IAligner::getProcessedCells (IAligner.hpp:377) */
+long long mi355sw_processed_cells(mi355sw_handle* h);
+int mi355sw_get_stats(mi355sw_handle* h, mi355sw_stats* out);
+
+/* ---- streaming form used by the column-band (multi-GPU) driver --------------------------------
+ * Replaces the reference's socket-fed border streams (M/common/io/SocketCells{Reader,Writer}.cpp,
+ * BufferedCells*.cpp) : the strip kernel runs once for the whole band while the host feeds the
+ * first column and drains the last column in row segments. */
+typedef struct {
+    int32_t recurrence_type;
+    int32_t first_row_init_type, first_row_start_offset;   /* InitialCellsReader startOffset */
+    const mi355sw_cell* first_row;      /* n+1 cells incl. corner when INIT_WITH_CUSTOM_DATA, else NULL */
+    int32_t first_column_init_type, first_column_start_offset;
+    int32_t stream_first_column;        /* 1: rows arrive through mi355sw_stream_feed_column() */
+    const mi355sw_cell* first_column;   /* m+1 cells incl. corner when CUSTOM and not streamed */
+    int32_t want_last_column;           /* keep (H,E) of column j1 for mi355sw_stream_read_column() */
+    int32_t want_last_row;
+    int32_t special_row_interval;       /* rows; 0 = none (rounded up to whole strips like
+                                           AbstractDiagonalAligner::isSpecialRow :466-478) */
+    int32_t track_best;                 /* mustDispatchScores() */
+} mi355sw_stream_params;
+
+int mi355sw_stream_begin(mi355sw_handle* h, const mi355sw_partition* partition, const mi355sw_stream_params* p);
+/* cells[0..len) = (H,E) of rows [row, row+len) of column j0-1 ; rows must arrive in order */
+int mi355sw_stream_feed_column(mi355sw_handle* h, int32_t row, const mi355sw_cell* cells, int32_t len);
+/* number of DP rows whose strips are complete (monotonic); *finished = 1 when the kernel ended */
+int mi355sw_stream_poll(mi355sw_handle* h, int32_t* rows_done, int32_t* finished);
+/* (H,E) of rows [row,row+len) of the last column; only rows < rows_done are valid */
+int mi355sw_stream_read_column(mi355sw_handle* h, int32_t row, mi355sw_cell* cells, int32_t len);
+/* special row k (0-based) / last row: n cells (H,F) of columns j0..j1-1, valid once its strip is done */
+int mi355sw_stream_read_special_row(mi355sw_handle* h, int32_t k, int32_t* dp_row, mi355sw_cell* cells, int32_t col, int32_t len);
+int mi355sw_stream_read_last_row(mi355sw_handle* h, mi355sw_cell* cells, int32_t col, int32_t len);
+int mi355sw_stream_abort(mi355sw_handle* h);
+/* waits for the kernel; best = canonical (max score, min i, min j), sequence-relative 0-based cell */
+int mi355sw_stream_end(mi355sw_handle* h, mi355sw_score* best, int32_t* n_special_rows);
+/* per-strip best scores of the finished stream (for dispatch_score); returns count written */
+int mi355sw_stream_strip_scores(mi355sw_handle* h, mi355sw_score* out, int32_t max_count);
+/* raw device pointers of the engine's column buffers, for peer-to-peer (xGMI) transfers by the
+ * caller (RCCL send/recv on these addresses); NULL if not allocated */
+void* mi355sw_stream_device_first_column(mi355sw_handle* h);
+void* mi355sw_stream_device_last_column(mi355sw_handle* h);
+/* tell the engine that rows [0,rows) of the device first-column buffer are now valid (after a
+ * device-side transfer the caller performed itself) */
+int mi355sw_stream_publish_first_column(mi355sw_handle* h, int32_t rows);
+
+/* device enumeration: X/cuda_util.cpp:191-287 (--list-gpus, GPU weights) */
+int mi355sw_device_count(void);
+int mi355sw_device_info(int32_t device, char* name, size_t name_len, int32_t* compute_units, int32_t* clock_mhz, int64_t* hbm_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI355SW_H_ */

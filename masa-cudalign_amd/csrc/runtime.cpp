@@ -1,0 +1,762 @@
+// Host runtime + C ABI of the MI355X Stage-1 engine (include/mi355sw.h).
+//
+// Replaces the host side of the reference's CUDA extension:
+//   X/CUDAligner.cpp   (setSequences :229-265, allocate/free :611-671, processDiagonal :202-209,
+//                       getSpecialRow/LastRow/LastColumn/BlockScores :355-452, setFirstRow/Column :461-504)
+//   X/cuda_util.cpp    (device selection :191-287)
+//   M/libmasa/aligners/AbstractDiagonalAligner.cpp (call order of the IManager hooks, :59-159, :286-456)
+// with one persistent strip kernel per partition instead of a launch pair + sync per external
+// diagonal (X/CUDAligner.cu:1261-1277), and streamed border columns instead of per-diagonal copies.
+//
+// There is NO CPU fallback: without a gfx950 device mi355sw_create() fails with MI355SW_ENOGPU.
+#include "../../include/mi355sw.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <ctime>
+#include <string>
+#include <vector>
+
+#include "sw_kernel.h"
+
+using namespace mi355sw;
+
+namespace {
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+};
+
+double now_ms() {
+    using namespace std::chrono;
+    return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
+}
+
+}  // namespace
+
+struct mi355sw_handle {
+    mi355sw_config cfg{};
+    int device = 0;
+    int compute_units = 256;
+    hipStream_t stream = nullptr;   // strip kernel
+    hipStream_t copy = nullptr;     // border traffic while the kernel runs
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::string err;
+
+    // sequences (X/CUDAligner.cpp:229-265)
+    bool have_seq = false;
+    int len0 = 0, len1 = 0;
+    DevBuf d_seq0, d_seq1;
+    bool profile = false;
+    int n_match_codes = 0, pad_code = 0;
+
+    // work buffers
+    DevBuf d_bus, d_first_col, d_last_col, d_special, d_last_row, d_progress, d_strip_best, d_ctrl;
+    int* h_pinned = nullptr;        // [0] strips_done (kernel->host) [16] first_col_ready (host->kernel)
+    std::vector<int4> strip_best_host;
+
+    // stream state
+    bool active = false;
+    mi355sw_partition part{};
+    mi355sw_stream_params sp{};
+    int m = 0, n = 0, R = 8, SH = 512, strips = 0, waves = 0;
+    int special_interval_strips = 0, n_special = 0;
+    long long special_pitch = 0;
+    int fed_rows = 0;
+    bool finished = false;
+    mi355sw_stats stats{};
+    std::atomic<long long> processed_total{0};
+    std::atomic<int> prog_strips{0}, prog_total{0};
+};
+
+#define FAIL(h, code, ...)                                   \
+    do {                                                     \
+        char _b[512];                                        \
+        snprintf(_b, sizeof(_b), __VA_ARGS__);               \
+        (h)->err = _b;                                       \
+        return (code);                                       \
+    } while (0)
+
+#define HIPCHK(h, expr)                                                                      \
+    do {                                                                                     \
+        hipError_t _e = (expr);                                                              \
+        if (_e != hipSuccess) FAIL(h, MI355SW_EHIP, "%s failed: %s", #expr, hipGetErrorString(_e)); \
+    } while (0)
+
+static int ensure(mi355sw_handle* h, DevBuf& b, size_t bytes) {
+    if (bytes <= b.cap && b.p) return MI355SW_OK;
+    if (b.p) { (void) hipFree(b.p); b.p = nullptr; b.cap = 0; }
+    size_t want = std::max<size_t>(bytes, 256);
+    hipError_t e = hipMalloc(&b.p, want);
+    if (e != hipSuccess) FAIL(h, MI355SW_ENOMEM, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+    b.cap = want;
+    return MI355SW_OK;
+}
+
+static void release(DevBuf& b) {
+    if (b.p) (void) hipFree(b.p);
+    b.p = nullptr;
+    b.cap = 0;
+}
+
+extern "C" {
+
+int mi355sw_abi_version(void) { return MI355SW_ABI_VERSION; }
+
+int mi355sw_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int mi355sw_device_info(int32_t device, char* name, size_t name_len, int32_t* cus, int32_t* clock_mhz,
+                        int64_t* hbm_bytes) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return MI355SW_EHIP;
+    if (name && name_len) snprintf(name, name_len, "%s (%s)", prop.name, prop.gcnArchName);
+    if (cus) *cus = prop.multiProcessorCount;
+    if (clock_mhz) *clock_mhz = prop.clockRate / 1000;
+    if (hbm_bytes) *hbm_bytes = (int64_t) prop.totalGlobalMem;
+    return MI355SW_OK;
+}
+
+int mi355sw_create(const mi355sw_config* config, mi355sw_handle** out) {
+    if (!out) return MI355SW_EINVAL;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return MI355SW_ENOGPU;
+    mi355sw_handle* h = new mi355sw_handle();
+    if (config) h->cfg = *config;
+    else { h->cfg.device = -1; }
+    int dev = h->cfg.device;
+    if (dev < 0) { if (hipGetDevice(&dev) != hipSuccess) dev = 0; }
+    if (dev >= count) { delete h; return MI355SW_ENOGPU; }
+    if (hipSetDevice(dev) != hipSuccess) { delete h; return MI355SW_EHIP; }
+    h->device = dev;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) { delete h; return MI355SW_EHIP; }
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        // the code object only carries gfx950 ISA (CDNA4); anything else cannot run it
+        delete h;
+        return MI355SW_ENOGPU;
+    }
+    h->compute_units = prop.multiProcessorCount;
+    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&h->copy, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess ||
+        hipHostMalloc((void**) &h->h_pinned, 256, hipHostMallocMapped) != hipSuccess) {
+        mi355sw_destroy(h);
+        return MI355SW_EHIP;
+    }
+    memset(h->h_pinned, 0, 256);
+    *out = h;
+    return MI355SW_OK;
+}
+
+void mi355sw_destroy(mi355sw_handle* h) {
+    if (!h) return;
+    (void) hipSetDevice(h->device);
+    if (h->active) { mi355sw_stream_abort(h); mi355sw_stream_end(h, nullptr, nullptr); }
+    release(h->d_seq0); release(h->d_seq1); release(h->d_bus); release(h->d_first_col);
+    release(h->d_last_col); release(h->d_special); release(h->d_last_row); release(h->d_progress);
+    release(h->d_strip_best); release(h->d_ctrl);
+    if (h->h_pinned) (void) hipHostFree(h->h_pinned);
+    if (h->ev0) (void) hipEventDestroy(h->ev0);
+    if (h->ev1) (void) hipEventDestroy(h->ev1);
+    if (h->stream) (void) hipStreamDestroy(h->stream);
+    if (h->copy) (void) hipStreamDestroy(h->copy);
+    delete h;
+}
+
+const char* mi355sw_last_error(mi355sw_handle* h) { return h ? h->err.c_str() : "null handle"; }
+
+int mi355sw_get_capabilities(mi355sw_handle* h, mi355sw_capabilities* c) {
+    if (!h || !c) return MI355SW_EINVAL;
+    memset(c, 0, sizeof(*c));
+    // X/CUDAligner.cpp:87-111 : everything but special columns / variable penalties;
+    // no texture limit on MI355X => no maximum sequence length (M/stage1/sw_stage1.cpp:362-375)
+    c->dispatch_last_cell = 1; c->dispatch_last_row = 1; c->dispatch_last_column = 1;
+    c->dispatch_special_row = 1; c->dispatch_special_column = 0;
+    c->dispatch_scores = 1; c->dispatch_block_scores = 0; c->dispatch_best_score = 1;
+    c->customize_first_row = 1; c->customize_first_column = 1;
+    c->process_partition = 1; c->variable_penalties = 0; c->block_pruning = 0;
+    c->needleman_wunsch = 1; c->smith_waterman = 1; c->fork_processes = 1;
+    c->maximum_seq0_len = 0; c->maximum_seq1_len = 0;
+    return MI355SW_OK;
+}
+
+int mi355sw_get_score_parameters(mi355sw_handle* h, mi355sw_score_params* p) {
+    if (!p) return MI355SW_EINVAL;
+    p->match = 1; p->mismatch = -3; p->gap_open = 3; p->gap_ext = 2;   // X/CUDAligner.hpp:77-98
+    return MI355SW_OK;
+}
+
+int mi355sw_set_sequences(mi355sw_handle* h, const char* seq0, const char* seq1, int32_t len0, int32_t len1) {
+    if (!h || !seq0 || !seq1 || len0 < 0 || len1 < 0) return MI355SW_EINVAL;
+    if (h->active) FAIL(h, MI355SW_ESTATE, "set_sequences while a stream is active");
+    HIPCHK(h, hipSetDevice(h->device));
+    const unsigned char* s0 = (const unsigned char*) seq0;
+    const unsigned char* s1 = (const unsigned char*) seq1;
+    bool in0[256] = {false}, in1[256] = {false};
+    for (int k = 0; k < len0; k++) in0[s0[k]] = true;
+    for (int k = 0; k < len1; k++) in1[s1[k]] = true;
+    int common = 0;
+    for (int b = 0; b < 256; b++) common += (in0[b] && in1[b]);
+    h->profile = (common <= 7) && !(h->cfg.flags & MI355SW_F_FORCE_GENERIC_COMPARE);
+    std::vector<unsigned char> c0((size_t) len0 + 64), c1((size_t) len1 + 64);
+    if (h->profile) {
+        // bytes present in both sequences get codes 0..K-1; every other byte can never match:
+        // code 7 in either sequence (profile nibble 7 is always "mismatch")
+        unsigned char lut[256];
+        int k = 0;
+        for (int b = 0; b < 256; b++) lut[b] = (in0[b] && in1[b]) ? (unsigned char) k++ : (unsigned char) 7;
+        h->n_match_codes = k;
+        h->pad_code = 7;
+        for (int i = 0; i < len0; i++) c0[i] = lut[s0[i]];
+        for (int j = 0; j < len1; j++) c1[j] = (unsigned char) (lut[s1[j]] * 4);   // v_bfe_i32 bit offset
+    } else {
+        h->n_match_codes = 256;
+        h->pad_code = 256;     // rows beyond m never equal any byte
+        memcpy(c0.data(), s0, (size_t) len0);
+        memcpy(c1.data(), s1, (size_t) len1);
+    }
+    int rc;
+    if ((rc = ensure(h, h->d_seq0, c0.size())) || (rc = ensure(h, h->d_seq1, c1.size()))) return rc;
+    HIPCHK(h, hipMemcpy(h->d_seq0.p, c0.data(), c0.size(), hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(h->d_seq1.p, c1.data(), c1.size(), hipMemcpyHostToDevice));
+    h->len0 = len0;
+    h->len1 = len1;
+    h->have_seq = true;
+    return MI355SW_OK;
+}
+
+int mi355sw_unset_sequences(mi355sw_handle* h) {
+    if (!h) return MI355SW_EINVAL;
+    if (h->active) FAIL(h, MI355SW_ESTATE, "unset_sequences while a stream is active");
+    h->have_seq = false;
+    return MI355SW_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// streaming form
+// ------------------------------------------------------------------------------------------------
+static int pick_rows_per_lane(const mi355sw_handle* h, int m) {
+    if (h->cfg.rows_per_lane == 4 || h->cfg.rows_per_lane == 8 || h->cfg.rows_per_lane == 16)
+        return h->cfg.rows_per_lane;
+    // enough strips to give every SIMD several wavefronts; taller strips amortise hand-offs
+    const long long slots = (long long) h->compute_units * 16;
+    if ((long long) m >= slots * 64 * 16 * 4) return 16;
+    if ((long long) m >= slots * 64 * 8) return 8;
+    if (m > 64 * 4 * 8) return 4;
+    return 4;
+}
+
+int mi355sw_stream_begin(mi355sw_handle* h, const mi355sw_partition* part, const mi355sw_stream_params* p) {
+    if (!h || !part || !p) return MI355SW_EINVAL;
+    if (!h->have_seq) FAIL(h, MI355SW_ESTATE, "stream_begin before set_sequences");
+    if (h->active) FAIL(h, MI355SW_ESTATE, "stream already active");
+    if (part->i0 < 0 || part->j0 < 0 || part->i1 > h->len0 || part->j1 > h->len1 || part->i1 <= part->i0 ||
+        part->j1 <= part->j0)
+        FAIL(h, MI355SW_EINVAL, "bad partition (%d,%d)-(%d,%d) for sequences %d x %d", part->i0, part->j0,
+             part->i1, part->j1, h->len0, h->len1);
+    HIPCHK(h, hipSetDevice(h->device));
+    h->part = *part;
+    h->sp = *p;
+    const int m = part->i1 - part->i0, n = part->j1 - part->j0;
+    h->m = m; h->n = n;
+    h->R = pick_rows_per_lane(h, m);
+    h->SH = 64 * h->R;
+    h->strips = (m + h->SH - 1) / h->SH;
+    int waves = h->cfg.waves > 0 ? h->cfg.waves : h->compute_units * 16;
+    if (waves > h->strips) waves = h->strips;
+    h->waves = waves;
+    h->finished = false;
+    h->fed_rows = 0;
+
+    // special rows: AbstractDiagonalAligner::isSpecialRow (:466-478): every K-th strip boundary,
+    // K = max(ceil(interval/bh), MINIMUM_FLUSH_INTERVAL/bh), never row 0 nor rows >= height
+    h->special_interval_strips = 0;
+    h->n_special = 0;
+    if (p->special_row_interval > 0) {
+        int K = (p->special_row_interval + h->SH - 1) / h->SH;
+        if (K <= 0) K = 1;
+        if (K <= 8192 / h->SH) K = 8192 / h->SH;
+        if (K < 1) K = 1;
+        h->special_interval_strips = K;
+        h->n_special = (int) (((long long) m - 1) / ((long long) K * h->SH));   // rows K*SH*k < m
+    }
+    h->special_pitch = ((long long) n + 63) / 64 * 64;
+
+    int rc;
+    if ((rc = ensure(h, h->d_bus, sizeof(int2) * ((size_t) n + 64)))) return rc;
+    if ((rc = ensure(h, h->d_progress, sizeof(int) * ((size_t) h->strips + 1)))) return rc;
+    if ((rc = ensure(h, h->d_strip_best, sizeof(int4) * (size_t) h->strips))) return rc;
+    if ((rc = ensure(h, h->d_ctrl, 256))) return rc;
+    const bool need_first_col = (p->first_column_init_type != MI355SW_INIT_WITH_ZEROES);
+    if (need_first_col && (rc = ensure(h, h->d_first_col, sizeof(int2) * ((size_t) m + 1)))) return rc;
+    if (p->want_last_column && (rc = ensure(h, h->d_last_col, sizeof(int2) * ((size_t) m + 1)))) return rc;
+    if (p->want_last_row && (rc = ensure(h, h->d_last_row, sizeof(int2) * ((size_t) n + 64)))) return rc;
+    if (h->n_special > 0) {
+        const size_t bytes = sizeof(int2) * (size_t) h->special_pitch * h->n_special;
+        const int64_t budget = h->cfg.max_special_bytes > 0 ? h->cfg.max_special_bytes : (8LL << 30);
+        if ((int64_t) bytes > budget)
+            FAIL(h, MI355SW_ENOMEM, "%d special rows need %zu bytes > budget %lld", h->n_special, bytes,
+                 (long long) budget);
+        if ((rc = ensure(h, h->d_special, bytes))) return rc;
+    }
+
+    // ---- borders ----
+    // first row -> bus (AbstractDiagonalAligner::loadFirstRow :409-426 / CUDAligner::setFirstRow :461-465)
+    if (p->first_row_init_type == MI355SW_INIT_WITH_CUSTOM_DATA) {
+        if (!p->first_row) FAIL(h, MI355SW_EINVAL, "custom first row without data");
+        HIPCHK(h, hipMemcpyAsync(h->d_bus.p, p->first_row + 1, sizeof(int2) * (size_t) n, hipMemcpyHostToDevice,
+                                 h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));   // caller's buffer is only borrowed
+    } else {
+        HIPCHK(h, launch_fill_bus((int2*) h->d_bus.p, n, p->first_row_init_type, p->first_row_start_offset,
+                                  h->stream));
+    }
+    // first column
+    h->h_pinned[16] = 0;
+    if (need_first_col) {
+        if (p->first_column_init_type == MI355SW_INIT_WITH_CUSTOM_DATA) {
+            if (!p->stream_first_column) {
+                if (!p->first_column) FAIL(h, MI355SW_EINVAL, "custom first column without data");
+                HIPCHK(h, hipMemcpyAsync(h->d_first_col.p, p->first_column, sizeof(int2) * ((size_t) m + 1),
+                                         hipMemcpyHostToDevice, h->stream));
+                HIPCHK(h, hipStreamSynchronize(h->stream));
+                h->h_pinned[16] = m;
+                h->fed_rows = m;
+            } else if (p->first_column) {
+                // only the corner is known up front
+                HIPCHK(h, hipMemcpyAsync(h->d_first_col.p, p->first_column, sizeof(int2), hipMemcpyHostToDevice,
+                                         h->stream));
+                HIPCHK(h, hipStreamSynchronize(h->stream));
+            }
+        } else {
+            // InitialCellsReader (InitialCellsReader.cpp:84-108) generated on the host once
+            std::vector<mi355sw_cell> col((size_t) m + 1);
+            const int open = (p->first_column_init_type == MI355SW_INIT_WITH_GAPS) ? 3 : 0;
+            for (int k = 0; k <= m; k++) {
+                const long long pos = (long long) p->first_column_start_offset + k;
+                col[k].h = (pos == 0) ? 0 : (int32_t) (-2 * pos - open);
+                col[k].f = -MI355SW_INF;
+            }
+            HIPCHK(h, hipMemcpyAsync(h->d_first_col.p, col.data(), sizeof(int2) * ((size_t) m + 1),
+                                     hipMemcpyHostToDevice, h->stream));
+            HIPCHK(h, hipStreamSynchronize(h->stream));
+            h->h_pinned[16] = m;
+            h->fed_rows = m;
+        }
+    }
+    // synchronisation words
+    HIPCHK(h, hipMemsetAsync(h->d_progress.p, 0, sizeof(int) * ((size_t) h->strips + 1), h->stream));
+    HIPCHK(h, launch_fill_int((int*) h->d_progress.p, 1, n, h->stream));   // virtual strip above: all columns ready
+    HIPCHK(h, hipMemsetAsync(h->d_ctrl.p, 0, 256, h->stream));
+    HIPCHK(h, hipMemsetAsync(h->d_strip_best.p, 0, sizeof(int4) * (size_t) h->strips, h->stream));
+    h->h_pinned[0] = 0;
+
+    KernelArgs a{};
+    a.seq0 = (const unsigned char*) h->d_seq0.p + part->i0;
+    a.seq1 = (const unsigned char*) h->d_seq1.p + part->j0;
+    a.m = m; a.n = n;
+    a.n_match_codes = h->n_match_codes;
+    a.pad_code = h->pad_code;
+    a.num_strips = h->strips;
+    a.strip_row0 = 0;
+    a.strip_index0 = 0;
+    a.bus = (int2*) h->d_bus.p;
+    a.first_col = need_first_col ? (const int2*) h->d_first_col.p : nullptr;
+    a.last_col = p->want_last_column ? (int2*) h->d_last_col.p : nullptr;
+    a.special_rows = h->n_special > 0 ? (int2*) h->d_special.p : nullptr;
+    a.special_pitch = h->special_pitch;
+    a.special_interval_strips = h->n_special > 0 ? h->special_interval_strips : 0;
+    a.last_row = p->want_last_row ? (int2*) h->d_last_row.p : nullptr;
+    a.progress = (int*) h->d_progress.p;
+    int* ctrl = (int*) h->d_ctrl.p;
+    a.ticket = ctrl + 0;
+    a.abort_flag = ctrl + 16;
+    a.error_flag = ctrl + 32;
+    a.strips_done_dev = ctrl + 48;
+    a.strips_done_host = h->h_pinned + 0;
+    a.first_col_ready = (need_first_col && p->stream_first_column) ? h->h_pinned + 16 : nullptr;
+    a.strip_best = (int4*) h->d_strip_best.p;
+
+    h->stats = mi355sw_stats{};
+    h->stats.cells = (int64_t) m * n;
+    h->stats.strips = h->strips;
+    h->stats.strip_rows = h->SH;
+    h->stats.waves = waves;
+    h->stats.profile_kernel = h->profile ? 1 : 0;
+    h->stats.kernel_launches = 1;
+    h->stats.total_ms = now_ms();
+    h->prog_strips = 0;
+    h->prog_total = h->strips;
+
+    HIPCHK(h, hipEventRecord(h->ev0, h->stream));
+    HIPCHK(h, launch_strip_kernel(a, h->R, waves, h->stream, p->recurrence_type == MI355SW_SMITH_WATERMAN,
+                                  h->profile, p->track_best != 0));
+    HIPCHK(h, hipEventRecord(h->ev1, h->stream));
+    h->active = true;
+    return MI355SW_OK;
+}
+
+int mi355sw_stream_feed_column(mi355sw_handle* h, int32_t row, const mi355sw_cell* cells, int32_t len) {
+    if (!h || !h->active) return MI355SW_ESTATE;
+    if (row != h->fed_rows || len < 0 || row + len > h->m) FAIL(h, MI355SW_EINVAL, "feed_column out of order");
+    if (len == 0) return MI355SW_OK;
+    HIPCHK(h, hipMemcpyAsync((int2*) h->d_first_col.p + 1 + row, cells, sizeof(int2) * (size_t) len,
+                             hipMemcpyHostToDevice, h->copy));
+    HIPCHK(h, hipStreamSynchronize(h->copy));
+    h->fed_rows += len;
+    __atomic_store_n(&h->h_pinned[16], h->fed_rows, __ATOMIC_RELEASE);
+    return MI355SW_OK;
+}
+
+int mi355sw_stream_publish_first_column(mi355sw_handle* h, int32_t rows) {
+    if (!h || !h->active) return MI355SW_ESTATE;
+    if (rows < h->fed_rows || rows > h->m) FAIL(h, MI355SW_EINVAL, "publish_first_column out of range");
+    h->fed_rows = rows;
+    __atomic_store_n(&h->h_pinned[16], rows, __ATOMIC_RELEASE);
+    return MI355SW_OK;
+}
+
+void* mi355sw_stream_device_first_column(mi355sw_handle* h) { return h ? h->d_first_col.p : nullptr; }
+void* mi355sw_stream_device_last_column(mi355sw_handle* h) { return h ? h->d_last_col.p : nullptr; }
+
+int mi355sw_stream_poll(mi355sw_handle* h, int32_t* rows_done, int32_t* finished) {
+    if (!h || !h->active) return MI355SW_ESTATE;
+    const int done = __atomic_load_n(&h->h_pinned[0], __ATOMIC_ACQUIRE);
+    h->prog_strips = done;
+    long long rows = (long long) done * h->SH;
+    if (rows > h->m) rows = h->m;
+    if (rows_done) *rows_done = (int32_t) rows;
+    if (!h->finished) {
+        hipError_t e = hipEventQuery(h->ev1);
+        if (e == hipSuccess) h->finished = true;
+        else if (e != hipErrorNotReady) FAIL(h, MI355SW_EHIP, "kernel failed: %s", hipGetErrorString(e));
+    }
+    if (finished) *finished = h->finished ? 1 : 0;
+    return MI355SW_OK;
+}
+
+int mi355sw_stream_read_column(mi355sw_handle* h, int32_t row, mi355sw_cell* cells, int32_t len) {
+    if (!h || !h->active || !h->sp.want_last_column) return MI355SW_ESTATE;
+    if (row < 0 || len < 0 || row + len > h->m) FAIL(h, MI355SW_EINVAL, "read_column range");
+    HIPCHK(h, hipMemcpyAsync(cells, (int2*) h->d_last_col.p + 1 + row, sizeof(int2) * (size_t) len,
+                             hipMemcpyDeviceToHost, h->copy));
+    HIPCHK(h, hipStreamSynchronize(h->copy));
+    return MI355SW_OK;
+}
+
+int mi355sw_stream_read_special_row(mi355sw_handle* h, int32_t k, int32_t* dp_row, mi355sw_cell* cells,
+                                    int32_t col, int32_t len) {
+    if (!h || !h->active) return MI355SW_ESTATE;
+    if (k < 0 || k >= h->n_special || col < 0 || len < 0 || col + len > h->n) FAIL(h, MI355SW_EINVAL, "special row range");
+    if (dp_row) *dp_row = (k + 1) * h->special_interval_strips * h->SH;
+    if (len > 0 && cells) {
+        HIPCHK(h, hipMemcpyAsync(cells, (int2*) h->d_special.p + (size_t) k * h->special_pitch + col,
+                                 sizeof(int2) * (size_t) len, hipMemcpyDeviceToHost, h->copy));
+        HIPCHK(h, hipStreamSynchronize(h->copy));
+    }
+    return MI355SW_OK;
+}
+
+int mi355sw_stream_read_last_row(mi355sw_handle* h, mi355sw_cell* cells, int32_t col, int32_t len) {
+    if (!h || !h->active || !h->sp.want_last_row) return MI355SW_ESTATE;
+    if (col < 0 || len < 0 || col + len > h->n) FAIL(h, MI355SW_EINVAL, "last row range");
+    HIPCHK(h, hipMemcpyAsync(cells, (int2*) h->d_last_row.p + col, sizeof(int2) * (size_t) len, hipMemcpyDeviceToHost,
+                             h->copy));
+    HIPCHK(h, hipStreamSynchronize(h->copy));
+    return MI355SW_OK;
+}
+
+int mi355sw_stream_abort(mi355sw_handle* h) {
+    if (!h || !h->active) return MI355SW_ESTATE;
+    int one = 1;
+    HIPCHK(h, hipMemcpyAsync((int*) h->d_ctrl.p + 16, &one, sizeof(int), hipMemcpyHostToDevice, h->copy));
+    HIPCHK(h, hipStreamSynchronize(h->copy));
+    // unblock strips waiting for first-column rows that will never come
+    __atomic_store_n(&h->h_pinned[16], h->m, __ATOMIC_RELEASE);
+    return MI355SW_OK;
+}
+
+int mi355sw_stream_end(mi355sw_handle* h, mi355sw_score* best, int32_t* n_special_rows) {
+    if (!h || !h->active) return MI355SW_ESTATE;
+    hipError_t e = hipStreamSynchronize(h->stream);
+    h->active = false;
+    h->finished = true;
+    if (e != hipSuccess) FAIL(h, MI355SW_EHIP, "strip kernel failed: %s", hipGetErrorString(e));
+    float ms = 0.f;
+    HIPCHK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    h->stats.kernel_ms = ms;
+    h->stats.total_ms = now_ms() - h->stats.total_ms;
+    int ctrl[64];
+    HIPCHK(h, hipMemcpy(ctrl, h->d_ctrl.p, sizeof(ctrl), hipMemcpyDeviceToHost));
+    const bool aborted = ctrl[16] != 0;
+    if (ctrl[32] != 0) FAIL(h, MI355SW_ETIMEOUT, "in-kernel wait timed out (code %d)", ctrl[32]);
+    h->strip_best_host.resize((size_t) h->strips);
+    HIPCHK(h, hipMemcpy(h->strip_best_host.data(), h->d_strip_best.p, sizeof(int4) * (size_t) h->strips,
+                        hipMemcpyDeviceToHost));
+    mi355sw_score b;
+    b.i = -1; b.j = -1; b.score = -MI355SW_INF;
+    if (h->sp.track_best) {
+        // canonical order of BestScoreList (M/common/BestScoreList.hpp:30-38): score desc, i asc, j asc
+        for (int s = 0; s < h->strips; s++) {
+            const int4 r = h->strip_best_host[(size_t) s];
+            if (r.w == 0 || r.z < 0) continue;
+            if (r.x > b.score || (r.x == b.score && (r.y < b.i || (r.y == b.i && r.z < b.j)))) {
+                b.score = r.x; b.i = r.y; b.j = r.z;
+            }
+        }
+        if (b.j >= 0) { b.i += h->part.i0; b.j += h->part.j0; }
+    }
+    if (best) *best = b;
+    if (n_special_rows) *n_special_rows = h->n_special;
+    const int done_strips = aborted ? ctrl[48] : h->strips;
+    h->stats.processed_cells = (int64_t) std::min<long long>((long long) done_strips * h->SH, h->m) * h->n;
+    h->processed_total += h->stats.processed_cells;
+    // 17 B per column per strip + seq0 once + flushed rows
+    h->stats.algorithmic_bytes = 17LL * h->n * h->strips + h->m + 8LL * (h->n + 1) * (h->n_special + (h->sp.want_last_row ? 1 : 0));
+    h->prog_strips = h->strips;
+    return MI355SW_OK;
+}
+
+int mi355sw_stream_strip_scores(mi355sw_handle* h, mi355sw_score* out, int32_t max_count) {
+    if (!h || !out) return MI355SW_EINVAL;
+    int cnt = 0;
+    for (size_t s = 0; s < h->strip_best_host.size() && cnt < max_count; s++) {
+        const int4 r = h->strip_best_host[s];
+        if (r.w == 0 || r.z < 0) continue;
+        out[cnt].score = r.x; out[cnt].i = r.y + h->part.i0; out[cnt].j = r.z + h->part.j0;
+        cnt++;
+    }
+    return cnt;
+}
+
+// ------------------------------------------------------------------------------------------------
+// IAligner::alignPartition on top of the streaming form
+// ------------------------------------------------------------------------------------------------
+int mi355sw_align_partition(mi355sw_handle* h, const mi355sw_partition* part, const mi355sw_manager* mg, void* user) {
+    if (!h || !part || !mg) return MI355SW_EINVAL;
+    const int m = part->i1 - part->i0, n = part->j1 - part->j0;
+    if (m <= 0 || n <= 0) return MI355SW_OK;   // AlignerManager.cpp:96-99: zero-area partition skipped
+    mi355sw_stream_params sp{};
+    sp.recurrence_type = mg->get_recurrence_type(user);
+    sp.first_row_init_type = mg->get_first_row_init_type(user);
+    sp.first_column_init_type = mg->get_first_column_init_type(user);
+    const bool want_special = mg->must_dispatch_special_rows && mg->must_dispatch_special_rows(user);
+    sp.special_row_interval = want_special ? mg->get_special_row_interval(user) : 0;
+    sp.want_last_row = mg->must_dispatch_last_row && mg->must_dispatch_last_row(user);
+    sp.want_last_column = mg->must_dispatch_last_column && mg->must_dispatch_last_column(user);
+    const bool want_scores = mg->must_dispatch_scores && mg->must_dispatch_scores(user);
+    const bool want_last_cell = mg->must_dispatch_last_cell && mg->must_dispatch_last_cell(user);
+    sp.track_best = want_scores;
+    if (want_last_cell) sp.want_last_row = 1;
+
+    // AbstractDiagonalAligner::prepareIterations (:76-104): corner from both borders, then the row
+    mi355sw_cell corner_c, corner_r;
+    mg->receive_first_column(user, &corner_c, 1);
+    mg->receive_first_row(user, &corner_r, 1);
+    mi355sw_cell first_col_tail = corner_c, first_row_tail = corner_r;
+
+    std::vector<mi355sw_cell> row_host, col_host;
+    if (sp.first_row_init_type != MI355SW_INIT_WITH_ZEROES) {
+        // generic path: take whatever the manager streams (gaps with any start offset, custom data)
+        row_host.resize((size_t) n + 1);
+        row_host[0] = corner_r;
+        const int CH = 1 << 20;
+        for (int j = 0; j < n; j += CH) mg->receive_first_row(user, row_host.data() + 1 + j, std::min(CH, n - j));
+        first_row_tail = row_host[(size_t) n];
+        sp.first_row_init_type = MI355SW_INIT_WITH_CUSTOM_DATA;
+        sp.first_row = row_host.data();
+    } else {
+        first_row_tail.h = 0; first_row_tail.f = -MI355SW_INF;
+    }
+    // AbstractDiagonalAligner::loadFirstRow (:419-422): first cell of the last column
+    {
+        mi355sw_cell c = first_row_tail;
+        c.f = -MI355SW_INF;
+        mg->dispatch_column(user, part->j1, &c, 1);
+    }
+    const int orig_col_type = sp.first_column_init_type;
+    if (orig_col_type != MI355SW_INIT_WITH_ZEROES) {
+        sp.first_column_init_type = MI355SW_INIT_WITH_CUSTOM_DATA;
+        sp.stream_first_column = 1;
+        col_host.resize(1);
+        col_host[0] = corner_c;
+        sp.first_column = col_host.data();
+    }
+    if (mg->must_continue && !mg->must_continue(user)) return MI355SW_OK;
+
+    int rc = mi355sw_stream_begin(h, part, &sp);
+    if (rc) return rc;
+    const int SH = h->SH;
+    std::vector<mi355sw_cell> buf((size_t) std::max(SH, 1 << 16));
+    std::vector<mi355sw_cell> col_tail_at_special;   // first-column cell of each special row
+    int fed = 0, col_sent = 0, special_sent = 0;
+    bool stopped = false;
+    std::vector<mi355sw_cell> rowbuf;
+    // first-column cells needed later for the leading cell of special/last rows
+    std::vector<mi355sw_cell> fc_cells;   // fc_cells[k] = first column cell of DP row (k+1)*SH (or m)
+    for (;;) {
+        // feed the first column in strip-sized chunks (AbstractDiagonalAligner::loadFirstColumn :433-456)
+        if (orig_col_type != MI355SW_INIT_WITH_ZEROES) {
+            int budget = 64;   // chunks per poll round, keeps the stream ahead without starving dispatches
+            while (fed < m && budget-- > 0) {
+                const int len = std::min(SH, m - fed);
+                mg->receive_first_column(user, buf.data(), len);
+                first_col_tail = buf[(size_t) len - 1];
+                fc_cells.push_back(first_col_tail);
+                if ((rc = mi355sw_stream_feed_column(h, fed, buf.data(), len))) { mi355sw_stream_abort(h); mi355sw_stream_end(h, nullptr, nullptr); return rc; }
+                fed += len;
+            }
+        }
+        int rows_done = 0, fin = 0;
+        if ((rc = mi355sw_stream_poll(h, &rows_done, &fin))) { mi355sw_stream_end(h, nullptr, nullptr); return rc; }
+        // special rows that are complete (AbstractDiagonalAligner::flushSpecialRows :286-317)
+        while (special_sent < h->n_special) {
+            const int dp_row = (special_sent + 1) * h->special_interval_strips * SH;
+            if (dp_row > rows_done) break;
+            mi355sw_cell c;
+            if (orig_col_type == MI355SW_INIT_WITH_ZEROES) { c.h = 0; }
+            else c = fc_cells[(size_t) dp_row / SH - 1];
+            c.f = -MI355SW_INF;
+            mg->dispatch_row(user, part->i0 + dp_row, &c, 1);
+            rowbuf.resize((size_t) n);
+            if ((rc = mi355sw_stream_read_special_row(h, special_sent, nullptr, rowbuf.data(), 0, n))) { mi355sw_stream_abort(h); mi355sw_stream_end(h, nullptr, nullptr); return rc; }
+            const int CH = 1 << 20;
+            for (int j = 0; j < n; j += CH) mg->dispatch_row(user, part->i0 + dp_row, rowbuf.data() + j, std::min(CH, n - j));
+            special_sent++;
+        }
+        // last column chunks (AbstractDiagonalAligner::flushLastColumn :361-372)
+        if (sp.want_last_column) {
+            while (col_sent < rows_done && !stopped) {
+                const int len = std::min(SH, rows_done - col_sent);
+                if ((rc = mi355sw_stream_read_column(h, col_sent, buf.data(), len))) { mi355sw_stream_abort(h); mi355sw_stream_end(h, nullptr, nullptr); return rc; }
+                mg->dispatch_column(user, part->j1, buf.data(), len);
+                col_sent += len;
+                if (mg->must_continue && !mg->must_continue(user)) stopped = true;
+            }
+        }
+        if (!stopped && mg->must_continue && !mg->must_continue(user)) stopped = true;
+        if (stopped && !fin) { mi355sw_stream_abort(h); }
+        if (fin && (stopped || (rows_done >= m && special_sent >= h->n_special && (!sp.want_last_column || col_sent >= m)))) break;
+        if (fin && rows_done < m) break;   // aborted kernel
+        if (!fin && fed >= m) {
+            // nothing to feed: sleep a little instead of hammering the runtime
+            struct timespec ts = {0, 200000};
+            nanosleep(&ts, nullptr);
+        }
+    }
+    // last row (AbstractDiagonalAligner::flushLastRow :325-353) and last cell (:378-386)
+    mi355sw_score best;
+    int nsp = 0;
+    std::vector<mi355sw_cell> lastrow;
+    if (!stopped && sp.want_last_row) {
+        lastrow.resize((size_t) n);
+        if ((rc = mi355sw_stream_read_last_row(h, lastrow.data(), 0, n))) { mi355sw_stream_end(h, nullptr, nullptr); return rc; }
+    }
+    if ((rc = mi355sw_stream_end(h, &best, &nsp))) return rc;
+    if (stopped) return MI355SW_OK;
+    if (mg->must_dispatch_last_row && mg->must_dispatch_last_row(user)) {
+        mi355sw_cell c = first_col_tail;
+        if (orig_col_type == MI355SW_INIT_WITH_ZEROES) c.h = 0;
+        c.f = -MI355SW_INF;
+        mg->dispatch_row(user, part->i1, &c, 1);
+        const int CH = 1 << 20;
+        for (int j = 0; j < n; j += CH) mg->dispatch_row(user, part->i1, lastrow.data() + j, std::min(CH, n - j));
+    }
+    if (want_scores) {
+        // AbstractDiagonalAligner::flushBlockScores (:392-403): one score per strip instead of per block
+        std::vector<mi355sw_score> sc((size_t) h->strips);
+        const int cnt = mi355sw_stream_strip_scores(h, sc.data(), h->strips);
+        for (int k = 0; k < cnt; k++) mg->dispatch_score(user, sc[(size_t) k], -1, -1);
+    }
+    if (want_last_cell) {
+        mi355sw_score s;
+        s.i = part->i1 - 1; s.j = part->j1 - 1; s.score = lastrow[(size_t) n - 1].h;
+        mg->dispatch_score(user, s, -1, -1);
+    }
+    return MI355SW_OK;
+}
+
+// AbstractBlockProcessor::processBlock seam (S3): one partition-shaped call with explicit borders.
+int mi355sw_process_block(mi355sw_handle* h, mi355sw_cell* row, mi355sw_cell* col, int32_t i0, int32_t j0,
+                          int32_t i1, int32_t j1, int32_t recurrence, mi355sw_score* best) {
+    if (!h || !row || !col) return MI355SW_EINVAL;
+    const int m = i1 - i0, n = j1 - j0;
+    if (m <= 0 || n <= 0) FAIL(h, MI355SW_EINVAL, "empty block");
+    mi355sw_partition part = {i0, j0, i1, j1};
+    mi355sw_stream_params sp{};
+    sp.recurrence_type = recurrence;
+    std::vector<mi355sw_cell> frow((size_t) n + 1);
+    frow[0].h = col[0].h; frow[0].f = -MI355SW_INF;
+    memcpy(frow.data() + 1, row, sizeof(mi355sw_cell) * (size_t) n);
+    sp.first_row_init_type = MI355SW_INIT_WITH_CUSTOM_DATA;
+    sp.first_row = frow.data();
+    sp.first_column_init_type = MI355SW_INIT_WITH_CUSTOM_DATA;
+    sp.first_column = col;
+    sp.want_last_column = 1;
+    sp.want_last_row = 1;
+    sp.track_best = 1;
+    int rc = mi355sw_stream_begin(h, &part, &sp);
+    if (rc) return rc;
+    mi355sw_score b;
+    // the kernel must be complete before the borders are read back
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    std::vector<mi355sw_cell> lr((size_t) n), lc((size_t) m);
+    if ((rc = mi355sw_stream_read_last_row(h, lr.data(), 0, n)) || (rc = mi355sw_stream_read_column(h, 0, lc.data(), m))) {
+        mi355sw_stream_end(h, nullptr, nullptr);
+        return rc;
+    }
+    if ((rc = mi355sw_stream_end(h, &b, nullptr))) return rc;
+    // CPUBlockProcessor.cpp:159-165: col[0] <- H(i0-1, j1-1) (diagonal for the block to the right)
+    col[0].h = row[n - 1].h;
+    memcpy(row, lr.data(), sizeof(mi355sw_cell) * (size_t) n);
+    memcpy(col + 1, lc.data(), sizeof(mi355sw_cell) * (size_t) m);
+    if (best) {
+        if (b.j < 0) { best->i = -1; best->j = -1; best->score = -MI355SW_INF; }
+        else *best = b;
+    }
+    return MI355SW_OK;
+}
+
+int mi355sw_match_last_column(mi355sw_handle* h, const mi355sw_cell* buffer, const mi355sw_cell* base, int32_t len,
+                              int32_t goal, mi355sw_match_result* out) {
+    if (!buffer || !base || !out) return MI355SW_EINVAL;
+    // AlignerUtils::matchColumn (M/libmasa/utils/AlignerUtils.cpp:50-107), gap_open = 3
+    out->found = 0; out->k = -1; out->score = 0; out->type = 0;
+    for (int k = 0; k < len; k++) {
+        const int sum_match = base[k].h + buffer[k].h;
+        const int sum_gap = base[k].f + buffer[k].f + 3;
+        if (sum_match == goal) { out->found = 1; out->k = k; out->score = base[k].h; out->type = 0; return MI355SW_OK; }
+        if (sum_gap == goal) { out->found = 1; out->k = k; out->score = base[k].f; out->type = 1; return MI355SW_OK; }
+        if (sum_match > goal || sum_gap > goal) { out->k = k; out->type = sum_match > goal ? -1 : -2; return MI355SW_OK; }
+    }
+    return MI355SW_OK;
+}
+
+int mi355sw_progress(mi355sw_handle* h, char* buf, size_t len) {
+    if (!h || !buf || !len) return MI355SW_EINVAL;
+    int done = h->h_pinned ? __atomic_load_n(&h->h_pinned[0], __ATOMIC_RELAXED) : 0;
+    snprintf(buf, len, "PROGRESS: %d/%d strips", done, h->prog_total.load());
+    return MI355SW_OK;
+}
+
+long long mi355sw_processed_cells(mi355sw_handle* h) { return h ? h->processed_total.load() : 0; }
+
+int mi355sw_get_stats(mi355sw_handle* h, mi355sw_stats* out) {
+    if (!h || !out) return MI355SW_EINVAL;
+    *out = h->stats;
+    return MI355SW_OK;
+}
+
+}  // extern "C"

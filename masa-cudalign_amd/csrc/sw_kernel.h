@@ -1,0 +1,50 @@
+// Shared declarations between the HIP kernels (sw_kernel.hip) and the host runtime (runtime.cpp).
+#ifndef MI355SW_KERNEL_H_
+#define MI355SW_KERNEL_H_
+
+#include <hip/hip_runtime.h>
+
+namespace mi355sw {
+
+enum { CHUNK = 64 };   // bus columns staged per hand-off (one per lane)
+
+// M/libmasa/IManager.hpp:36-47
+enum { INIT_WITH_ZEROES = 0, INIT_WITH_GAPS = 1, INIT_WITH_CUSTOM_DATA = 2, INIT_WITH_GAPS_OPENED = 3 };
+
+struct KernelArgs {
+    // problem
+    const unsigned char* seq0;   // m codes (vertical)
+    const unsigned char* seq1;   // n shift codes (code*4) or raw bytes, padded to a multiple of 64
+    int m, n;
+    int n_match_codes;           // PROFILE: codes < this can match; others never do
+    int pad_code;                // code used for rows >= m
+    // strip geometry
+    int num_strips;              // strips in this launch
+    int strip_row0;              // DP row of strip 0 of this launch
+    int strip_index0;            // global ordinal of strip 0 (for special-row spacing)
+    // buses (HBM)
+    int2* bus;                   // n cells (H,F): row above on entry, emit row of the last strip on exit
+    const int2* first_col;       // m+1 cells (H,E) incl. corner, or nullptr => INIT_WITH_ZEROES
+    int2* last_col;              // m+1 cells (H,E) or nullptr
+    int2* special_rows;          // slot k = k * special_pitch cells, or nullptr
+    long long special_pitch;
+    int special_interval_strips; // every K-th strip end is flushed (0 = none)
+    int2* last_row;              // n cells (H,F) of DP row m, or nullptr
+    // synchronisation / results
+    int* progress;               // num_strips+1 ints; progress[0] = n (virtual strip above)
+    int* ticket;                 // next strip to claim
+    int* abort_flag;             // host sets != 0 to stop (mustContinue() == false)
+    int* error_flag;             // set by the kernel on a bounded-spin timeout
+    const int* first_col_ready;  // pinned host counter: rows of first_col that are valid, or nullptr (all)
+    int* strips_done_dev;        // device counter, ordered: value s means strips [0,s) complete
+    int* strips_done_host;       // pinned host mirror (system scope)
+    int4* strip_best;            // per strip {score, i, j, valid}
+};
+
+hipError_t launch_strip_kernel(const KernelArgs& a, int rows_per_lane, int grid, hipStream_t stream,
+                               bool sw, bool profile, bool track);
+hipError_t launch_fill_bus(int2* bus, int n, int init_type, int start_offset, hipStream_t stream);
+hipError_t launch_fill_int(int* p, long long count, int value, hipStream_t stream);
+
+}  // namespace mi355sw
+#endif

@@ -1,0 +1,419 @@
+// MI355X (gfx950 / CDNA4) Stage-1 affine-gap SW/NW strip-wavefront kernel.
+//
+// Replaces the reference's device code (X/CUDAligner.cu: kernel_long_phase :941-1007,
+// kernel_short_phase :745-824, kernel_single_phase :1100-1156, kernel_sw :276-289,
+// kernel_check_max4 :396-410, kernel_load :441-459, kernel_flush :502-540) with a
+// from-scratch design for 64-lane wavefronts:
+//
+//   * one wavefront owns a STRIP of 64*R consecutive DP rows (lane k: rows k*R..k*R+R-1, all
+//     state in VGPRs) and sweeps it left->right over the whole partition width; lane k is k
+//     columns behind lane k-1 (systolic skew), so every step each lane computes R cells of one
+//     column and hands its bottom (H,F) to lane k+1 with a single DPP wave_shr:1 move;
+//   * the horizontal bus row (H,F per column, HBM) is read in coalesced 64-column chunks,
+//     staged through LDS and fed to lane 0; lane 63's outputs are collected in LDS and written
+//     back in coalesced chunks (in place: a strip overwrites the bus row it consumed);
+//   * strips are claimed dynamically (atomic ticket) by persistent wavefronts; strip s+1
+//     follows strip s through a per-strip progress counter (write-through sc1 stores + drained
+//     flag, MI355X_MICROARCH.md "Valid forms") -- no kernel launch per external diagonal;
+//   * arithmetic is kept in the "t = H - (open+ext)" domain so that one subtraction per cell
+//     feeds both E of the right neighbour and F of the lower neighbour, the substitution score
+//     is one v_bfe_i32 from a per-row 8x4-bit profile register, H is v_max3 + v_max, and the
+//     running best is folded with v_max3 -- ~9.5 int32 VALU ops per SW cell.
+//
+// Recurrence (bit-identical to CPUBlockProcessor.cpp:66-93 and CUDAligner.cu:276-289):
+//   E = max(Hleft-3, Eleft)-2 ; F = max(Hup-3, Fup)-2 ; v = Hdiag + (c0!=c1 ? -3 : +1)
+//   H = SW ? max(0,v,E,F) : max(v,E,F)
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "sw_kernel.h"
+
+namespace mi355sw {
+
+#define GAP_FIRST 5   // DNA_GAP_OPEN + DNA_GAP_EXT (CUDAligner.hpp:92-98)
+#define GAP_EXT 2
+#define NEG_INF (-999999999)   // libmasaTypes.hpp:46
+
+typedef unsigned int u32;
+typedef __attribute__((address_space(1))) int gint;
+typedef __attribute__((address_space(1))) unsigned long long gu64;
+
+__device__ __forceinline__ int wave_shr1(int old, int src) {
+    // lane k <- src of lane k-1 ; lane 0 keeps `old` (DPP wave_shr:1, bound_ctrl off)
+    return __builtin_amdgcn_update_dpp(old, src, 0x138, 0xf, 0xf, false);
+}
+__device__ __forceinline__ int max3(int a, int b, int c) {
+    return max(max(a, b), c);   // folds to v_max3_i32
+}
+__device__ __forceinline__ int ld_agent(const int* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_agent(int* p, int v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ int2 ld_agent2(const int2* p) {
+    unsigned long long x = __hip_atomic_load((const unsigned long long*) p, __ATOMIC_RELAXED,
+                                             __HIP_MEMORY_SCOPE_AGENT);
+    return make_int2((int) (u32) x, (int) (u32) (x >> 32));
+}
+__device__ __forceinline__ void st_agent2(int2* p, int2 v) {
+    unsigned long long x = ((unsigned long long) (u32) v.y << 32) | (u32) v.x;
+    __hip_atomic_store((unsigned long long*) p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ int ld_sys(const int* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ int2 ld_sys2(const int2* p) {
+    unsigned long long x = __hip_atomic_load((const unsigned long long*) p, __ATOMIC_RELAXED,
+                                             __HIP_MEMORY_SCOPE_SYSTEM);
+    return make_int2((int) (u32) x, (int) (u32) (x >> 32));
+}
+
+// Per-wave LDS staging area (all values in the t = H-5 domain).
+struct __attribute__((aligned(16))) WaveLds {
+    int2 in_tf[CHUNK + 1];    // (t,F) of the row above, columns [64c, 64c+64) (+1: prefetch slot)
+    int2 out_tf[CHUNK];       // (t,F) of the emit row, written by the emit lane at step u
+    unsigned char c1[2 * CHUNK + 8];   // seq1 shift codes: [0,64) previous chunk, [64,128) current
+    int red[3 * 64];          // strip-end best reduction
+};
+
+template <int R>
+struct LaneState {
+    int tl[R];      // t (= H-5) of the cell to the left, per row
+    int e[R];       // E of the cell to the left, per row
+    int prof[R];    // PROFILE: 8 nibbles (c1 code -> score+5) ; else raw seq0 byte
+    int tup_prev;   // t of (row above, previous column)
+    int tbot, fbot; // bottom (t,F) produced at the previous step
+    int best_t, best_r, best_j;
+};
+
+// One systolic step: every lane advances one column.  `u` is the step index inside the chunk.
+template <int R, bool SW, bool PROFILE, bool MASKED, bool TRACK, bool EMIT_ANY>
+__device__ __forceinline__ void wave_step(LaneState<R>& st, WaveLds* lds, const int u, const int lane,
+                                          const int jl /* column of this lane at u=0 */, const int n,
+                                          const int nvalid, const int emit_lane, const int emit_row,
+                                          int2& feed_io, int& c1_io) {
+    // ---- hand-off from the lane above (full EXEC); LDS reads are software-pipelined by one step ----
+    const int2 feed = feed_io;                             // (t,F) of the row above: lane 0 only
+    const int c1 = c1_io;
+    feed_io = lds->in_tf[u + 1];                           // broadcast read for the next step
+    c1_io = lds->c1[CHUNK + u + 1 - lane];
+    const int tup = wave_shr1(feed.x, st.tbot);
+    const int fup = wave_shr1(feed.y, st.fbot);
+
+    bool active = true;
+    if (MASKED) active = (u32) (jl + u) < (u32) n;
+    if (active) {
+        int diag = st.tup_prev;
+        int upt = tup, upf = fup;
+        int t_emit = 0, f_emit = 0;
+        int mx = NEG_INF, tprev = NEG_INF;
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const int E = max(st.tl[r], st.e[r] - GAP_EXT);
+            const int F = max(upt, upf - GAP_EXT);
+            int v;
+            if (PROFILE) {
+                v = diag + __builtin_amdgcn_sbfe(st.prof[r], c1, 4);   // score+5 in {2,6}
+            } else {
+                v = diag + ((st.prof[r] != c1) ? 2 : 6);
+            }
+            int h = max3(v, E, F);
+            if (SW) h = max(h, 0);
+            const int t = h - GAP_FIRST;
+            diag = st.tl[r];
+            st.tl[r] = t;
+            st.e[r] = E;
+            upt = t;
+            upf = F;
+            if (TRACK) { if (r & 1) mx = max3(mx, tprev, t); tprev = t; }
+            if (EMIT_ANY) {
+                t_emit = (r == emit_row) ? t : t_emit;
+                f_emit = (r == emit_row) ? F : f_emit;
+            }
+        }
+        if (TRACK && (R & 1)) mx = max(mx, tprev);
+        st.tup_prev = tup;
+        st.tbot = upt;
+        st.fbot = upf;
+        if (!EMIT_ANY) { t_emit = upt; f_emit = upf; }
+        if (lane == emit_lane) lds->out_tf[u] = make_int2(t_emit, f_emit);
+
+        if (TRACK) {
+            // rare path: exact canonical (max score, min i, min j) bookkeeping
+            if (__any(mx >= st.best_t)) {
+                const int j = jl + u;
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    const int t = st.tl[r];
+                    const bool upd = (r < nvalid) && ((t > st.best_t) || (t == st.best_t && r < st.best_r));
+                    st.best_t = upd ? t : st.best_t;
+                    st.best_r = upd ? r : st.best_r;
+                    st.best_j = upd ? j : st.best_j;
+                }
+            }
+        }
+    }
+}
+
+template <int R, bool SW, bool PROFILE, bool TRACK>
+__global__ void __launch_bounds__(64) sw_strip_kernel(KernelArgs a) {
+    __shared__ WaveLds lds_store;
+    WaveLds* lds = &lds_store;
+    const int lane = threadIdx.x;
+    const int n = a.n;
+    const int SH = 64 * R;
+    const int nchunks = (n + 63 + CHUNK - 1) / CHUNK;
+
+    for (;;) {
+        // ---- claim the next strip (ordered tickets => forward progress) ----
+        int s = 0;
+        if (lane == 0) s = atomicAdd(a.ticket, 1);
+        s = __builtin_amdgcn_readfirstlane(s);
+        if (s >= a.num_strips) break;
+        if (ld_agent(a.abort_flag) != 0) {
+            // publish completion so that followers do not spin forever
+            if (lane == 0) st_agent(&a.progress[s + 1], n);
+            continue;
+        }
+        const int row0 = a.strip_row0 + s * SH;          // first DP row of this strip (0-based)
+        const int lrow0 = row0 + lane * R;                // first row of this lane
+        const int rows_left = a.m - lrow0;
+        const int nvalid = rows_left < 0 ? 0 : (rows_left > R ? R : rows_left);
+        const int* prog_in = &a.progress[s];              // progress of the strip above
+        int* prog_out = &a.progress[s + 1];
+
+        // which (lane,row) is the row handed to the next strip / flushed as special row
+        int emit_lane = 63, emit_row = R - 1;
+        const bool ragged = (row0 + SH > a.m);
+        if (ragged) {
+            const int last = a.m - 1 - row0;              // last valid row inside the strip
+            emit_lane = last / R;
+            emit_row = last - emit_lane * R;
+        }
+        const bool last_strip = (row0 + SH >= a.m);
+        int2* special = nullptr;
+        if (a.special_interval_strips > 0 && a.special_rows != nullptr) {
+            const int sg = a.strip_index0 + s + 1;       // strips completed once this one ends
+            if (sg % a.special_interval_strips == 0 && (long long) sg * SH < a.m)
+                special = a.special_rows + (long long) (sg / a.special_interval_strips - 1) * a.special_pitch;
+        }
+        int2* lastrow = (last_strip && a.last_row != nullptr) ? a.last_row : nullptr;
+
+        // ---- per-lane state from the first column (InitialCellsReader semantics on device) ----
+        if (a.first_col != nullptr && a.first_col_ready != nullptr) {
+            int need = row0 + SH;                         // rows [0,need) of the first column
+            if (need > a.m) need = a.m;
+            int spins = 0;
+            while (ld_sys(a.first_col_ready) < need) {
+                __builtin_amdgcn_s_sleep(32);
+                if (ld_agent(a.abort_flag) != 0) break;
+                if (++spins > (1 << 28)) { if (lane == 0) atomicExch(a.error_flag, 2); break; }
+            }
+        }
+        LaneState<R> st;
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            int h = 0, e = NEG_INF;
+            if (a.first_col != nullptr) {
+                const int g = lrow0 + r;
+                if (g < a.m) {
+                    const int2 c = ld_sys2(&a.first_col[g + 1]);
+                    h = c.x; e = c.y;
+                }
+            }
+            st.tl[r] = h - GAP_FIRST;
+            st.e[r] = e;
+            const int g = lrow0 + r;
+            const int c0 = (g < a.m) ? (int) a.seq0[g] : a.pad_code;
+            if (PROFILE) {
+                // nibble k = score(c0, code k) + 5 : 6 on match, 2 otherwise; pad/foreign codes never match
+                u32 p = 0x22222222u;
+                if (c0 < a.n_match_codes) p += (4u << (4 * c0));
+                st.prof[r] = (int) p;
+            } else {
+                st.prof[r] = c0;
+            }
+        }
+        {
+            int hd = 0;
+            if (a.first_col != nullptr && lrow0 <= a.m) hd = ld_sys2(&a.first_col[lrow0]).x;
+            st.tup_prev = hd - GAP_FIRST;
+        }
+        st.tbot = NEG_INF; st.fbot = NEG_INF;
+        st.best_t = NEG_INF; st.best_r = R; st.best_j = -1;
+
+        // ---- sweep the strip ----
+        for (int c = 0; c < nchunks; c++) {
+            const int col0 = c * CHUNK;
+            // (1) input chunk: wait for the strip above, then stage bus + seq1 codes into LDS
+            {
+                int need = col0 + CHUNK;
+                if (need > n) need = n;
+                if (col0 < n) {
+                    int spins = 0;
+                    while (ld_agent(prog_in) < need) {
+                        __builtin_amdgcn_s_sleep(2);
+                        if (++spins > (1 << 26)) { if (lane == 0) atomicExch(a.error_flag, 1); break; }
+                    }
+                }
+                const int col = col0 + lane;
+                int2 hf = make_int2(0, NEG_INF);
+                unsigned char code = 0;
+                if (col < n) {
+                    hf = ld_agent2(&a.bus[col]);
+                    code = a.seq1[col];
+                }
+                // shift the seq1 window: [64,128) -> [0,64), then the new chunk
+                const unsigned char prev = lds->c1[CHUNK + lane];
+                lds->c1[lane] = prev;
+                lds->c1[CHUNK + lane] = code;
+                lds->in_tf[lane] = make_int2(hf.x - GAP_FIRST, hf.y);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
+            // (2) 64 systolic steps
+            const int jl = col0 - lane;
+            const bool masked = (c == 0) || (col0 + CHUNK - 1 >= n);
+            int2 feed = lds->in_tf[0];
+            int c1 = lds->c1[CHUNK - lane];
+            if (ragged) {
+#pragma unroll 2
+                for (int u = 0; u < CHUNK; u++)
+                    wave_step<R, SW, PROFILE, true, TRACK, true>(st, lds, u, lane, jl, n, nvalid, emit_lane, emit_row, feed, c1);
+            } else if (masked) {
+#pragma unroll 2
+                for (int u = 0; u < CHUNK; u++)
+                    wave_step<R, SW, PROFILE, true, TRACK, false>(st, lds, u, lane, jl, n, nvalid, 63, R - 1, feed, c1);
+            } else {
+#pragma unroll 4
+                for (int u = 0; u < CHUNK; u++)
+                    wave_step<R, SW, PROFILE, false, TRACK, false>(st, lds, u, lane, jl, n, nvalid, 63, R - 1, feed, c1);
+            }
+            // (3) output chunk: columns col0-emit_lane .. col0-emit_lane+63
+            {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                const int2 tf = lds->out_tf[lane];
+                const int col = col0 - emit_lane + lane;
+                if (col >= 0 && col < n) {
+                    const int2 hf = make_int2(tf.x + GAP_FIRST, tf.y);
+                    st_agent2(&a.bus[col], hf);
+                    if (special != nullptr) special[col] = hf;
+                    if (lastrow != nullptr) lastrow[col] = hf;
+                }
+                // every store of this wave must have left before the flag (R1: drain, then flag)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                int done = col0 - emit_lane + CHUNK;
+                if (done > n) done = n;
+                if (done < 0) done = 0;
+                if (lane == 0) st_agent(prog_out, done);
+            }
+        }
+
+        // ---- strip epilogue: last column, best score ----
+        if (a.last_col != nullptr) {
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const int g = lrow0 + r;
+                if (g < a.m) a.last_col[g + 1] = make_int2(st.tl[r] + GAP_FIRST, st.e[r]);
+            }
+        }
+        if (TRACK) {
+            // canonical reduction over lanes: max t, then min row, then min j
+            lds->red[lane] = st.best_t;
+            lds->red[64 + lane] = (st.best_j >= 0) ? (lrow0 + st.best_r) : 0x7fffffff;
+            lds->red[128 + lane] = st.best_j;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (lane == 0) {
+                int bt = NEG_INF, bi = 0x7fffffff, bj = -1;
+                for (int k = 0; k < 64; k++) {
+                    const int t = lds->red[k], i = lds->red[64 + k], j = lds->red[128 + k];
+                    if (j >= 0 && (t > bt || (t == bt && (i < bi || (i == bi && j < bj))))) {
+                        bt = t; bi = i; bj = j;
+                    }
+                }
+                int4 rec;
+                rec.x = (bj >= 0) ? bt + GAP_FIRST : NEG_INF;
+                rec.y = bi; rec.z = bj; rec.w = 1;
+                a.strip_best[s] = rec;
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        // ---- ordered completion: strips_done == s+1 means strips 0..s are complete and their
+        //      last-column / special-row / best records are visible to the host (system scope) ----
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+        if (lane == 0) {
+            int spins = 0;
+            while (ld_agent(a.strips_done_dev) != s) {
+                __builtin_amdgcn_s_sleep(8);
+                if (++spins > (1 << 26)) { atomicExch(a.error_flag, 3); break; }
+            }
+            __hip_atomic_store(a.strips_done_host, s + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            st_agent(a.strips_done_dev, s + 1);
+        }
+    }
+}
+
+// Device-side border initialisation: InitialCellsReader::read (InitialCellsReader.cpp:84-108)
+__global__ void fill_bus_kernel(int2* bus, int n, int init_type, int start_offset) {
+    const int stride = gridDim.x * blockDim.x;
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += stride) {
+        int h = 0;
+        if (init_type == INIT_WITH_GAPS) h = -GAP_EXT * (start_offset + j + 1) - 3;
+        else if (init_type == INIT_WITH_GAPS_OPENED) h = -GAP_EXT * (start_offset + j + 1);
+        bus[j] = make_int2(h, NEG_INF);
+    }
+}
+
+__global__ void fill_int_kernel(int* p, long long count, int value) {
+    const long long stride = (long long) gridDim.x * blockDim.x;
+    for (long long k = (long long) blockIdx.x * blockDim.x + threadIdx.x; k < count; k += stride) p[k] = value;
+}
+
+template <int R>
+static hipError_t launch_r(const KernelArgs& a, int grid, hipStream_t stream, bool sw, bool profile, bool track) {
+#define LAUNCH(SWV, PRV, TRV) \
+    hipLaunchKernelGGL((sw_strip_kernel<R, SWV, PRV, TRV>), dim3(grid), dim3(64), 0, stream, a)
+    if (sw) {
+        if (profile) { if (track) LAUNCH(true, true, true); else LAUNCH(true, true, false); }
+        else         { if (track) LAUNCH(true, false, true); else LAUNCH(true, false, false); }
+    } else {
+        if (profile) { if (track) LAUNCH(false, true, true); else LAUNCH(false, true, false); }
+        else         { if (track) LAUNCH(false, false, true); else LAUNCH(false, false, false); }
+    }
+#undef LAUNCH
+    return hipGetLastError();
+}
+
+hipError_t launch_strip_kernel(const KernelArgs& a, int rows_per_lane, int grid, hipStream_t stream,
+                               bool sw, bool profile, bool track) {
+    switch (rows_per_lane) {
+    case 4: return launch_r<4>(a, grid, stream, sw, profile, track);
+    case 8: return launch_r<8>(a, grid, stream, sw, profile, track);
+    case 16: return launch_r<16>(a, grid, stream, sw, profile, track);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_fill_bus(int2* bus, int n, int init_type, int start_offset, hipStream_t stream) {
+    int blocks = (n + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(fill_bus_kernel, dim3(blocks), dim3(256), 0, stream, bus, n, init_type, start_offset);
+    return hipGetLastError();
+}
+
+hipError_t launch_fill_int(int* p, long long count, int value, hipStream_t stream) {
+    long long b = (count + 255) / 256;
+    int blocks = (int) (b > 2048 ? 2048 : (b < 1 ? 1 : b));
+    hipLaunchKernelGGL(fill_int_kernel, dim3(blocks), dim3(256), 0, stream, p, count, value);
+    return hipGetLastError();
+}
+
+}  // namespace mi355sw

@@ -1,0 +1,418 @@
+"""ctypes binding of the C ABI (include/mi355sw.h) + Python mirror of the IAligner surface.
+
+Method names follow MASA-Core's IAligner (M/libmasa/IAligner.hpp:159-377) so the parity tests read
+like a MASA extension would be driven: getCapabilities / setSequences / alignPartition / ...
+There is no CPU fallback: if libmi355sw.so is missing or no gfx950 GPU is present, construction
+raises AlignerError.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libmi355sw.so")
+INCLUDE_PATH = os.path.join(os.path.dirname(HERE), "include", "mi355sw.h")
+
+INF = 999999999
+NEEDLEMAN_WUNSCH, SMITH_WATERMAN = 0, 1
+INIT_WITH_ZEROES, INIT_WITH_GAPS, INIT_WITH_CUSTOM_DATA, INIT_WITH_GAPS_OPENED = 0, 1, 2, 3
+
+ERRORS = {-1: "EINVAL", -2: "EHIP", -3: "ENOGPU", -4: "ENOMEM", -5: "ETIMEOUT", -6: "ESTATE"}
+
+
+class AlignerError(RuntimeError):
+    pass
+
+
+class Cell(C.Structure):
+    _fields_ = [("h", C.c_int32), ("f", C.c_int32)]
+
+
+class Score(C.Structure):
+    _fields_ = [("i", C.c_int32), ("j", C.c_int32), ("score", C.c_int32)]
+
+
+class ScoreParams(C.Structure):
+    _fields_ = [("match", C.c_int32), ("mismatch", C.c_int32), ("gap_open", C.c_int32), ("gap_ext", C.c_int32)]
+
+
+class MatchResult(C.Structure):
+    _fields_ = [("found", C.c_int32), ("k", C.c_int32), ("score", C.c_int32), ("type", C.c_int32)]
+
+
+class Partition(C.Structure):
+    """M/libmasa/Partition.hpp: half-open [i0,i1) x [j0,j1), sequence-relative."""
+    _fields_ = [("i0", C.c_int32), ("j0", C.c_int32), ("i1", C.c_int32), ("j1", C.c_int32)]
+
+    def __init__(self, i0=0, j0=0, i1=0, j1=0):
+        super().__init__(i0, j0, i1, j1)
+
+    def getHeight(self):
+        return self.i1 - self.i0
+
+    def getWidth(self):
+        return self.j1 - self.j0
+
+
+class Config(C.Structure):
+    _fields_ = [("device", C.c_int32), ("rows_per_lane", C.c_int32), ("waves", C.c_int32),
+                ("flags", C.c_int32), ("max_special_bytes", C.c_int64)]
+
+
+class Capabilities(C.Structure):
+    _fields_ = [(k, C.c_int32) for k in (
+        "dispatch_last_cell", "dispatch_last_row", "dispatch_last_column",
+        "dispatch_special_row", "dispatch_special_column",
+        "dispatch_scores", "dispatch_block_scores", "dispatch_best_score",
+        "customize_first_row", "customize_first_column",
+        "process_partition", "variable_penalties", "block_pruning",
+        "needleman_wunsch", "smith_waterman", "fork_processes",
+        "maximum_seq0_len", "maximum_seq1_len")]
+
+
+class Stats(C.Structure):
+    _fields_ = [("cells", C.c_int64), ("processed_cells", C.c_int64), ("kernel_ms", C.c_double),
+                ("total_ms", C.c_double), ("kernel_launches", C.c_int32), ("strips", C.c_int32),
+                ("strip_rows", C.c_int32), ("waves", C.c_int32), ("profile_kernel", C.c_int32),
+                ("algorithmic_bytes", C.c_int64)]
+
+
+class StreamParams(C.Structure):
+    _fields_ = [("recurrence_type", C.c_int32),
+                ("first_row_init_type", C.c_int32), ("first_row_start_offset", C.c_int32),
+                ("first_row", C.c_void_p),
+                ("first_column_init_type", C.c_int32), ("first_column_start_offset", C.c_int32),
+                ("stream_first_column", C.c_int32),
+                ("first_column", C.c_void_p),
+                ("want_last_column", C.c_int32), ("want_last_row", C.c_int32),
+                ("special_row_interval", C.c_int32), ("track_best", C.c_int32)]
+
+
+_VP = C.c_void_p
+CB_INT = C.CFUNCTYPE(C.c_int32, _VP)
+CB_PART = C.CFUNCTYPE(None, _VP, C.POINTER(Partition))
+CB_RECV = C.CFUNCTYPE(None, _VP, C.POINTER(Cell), C.c_int32)
+CB_DISP = C.CFUNCTYPE(None, _VP, C.c_int32, C.POINTER(Cell), C.c_int32)
+CB_SCORE = C.CFUNCTYPE(None, _VP, Score, C.c_int32, C.c_int32)
+
+
+class ManagerTable(C.Structure):
+    _fields_ = [("get_recurrence_type", CB_INT), ("get_special_row_interval", CB_INT),
+                ("get_first_column_init_type", CB_INT), ("get_first_row_init_type", CB_INT),
+                ("get_super_partition", CB_PART),
+                ("receive_first_row", CB_RECV), ("receive_first_column", CB_RECV),
+                ("dispatch_column", CB_DISP), ("dispatch_row", CB_DISP), ("dispatch_score", CB_SCORE),
+                ("must_continue", CB_INT), ("must_dispatch_last_cell", CB_INT),
+                ("must_dispatch_last_row", CB_INT), ("must_dispatch_last_column", CB_INT),
+                ("must_dispatch_special_rows", CB_INT), ("must_dispatch_scores", CB_INT),
+                ("must_prune_blocks", CB_INT)]
+
+
+# every symbol include/mi355sw.h declares (tests check the .so exports all of them)
+ABI_SYMBOLS = [
+    "mi355sw_create", "mi355sw_destroy", "mi355sw_last_error", "mi355sw_abi_version",
+    "mi355sw_get_capabilities", "mi355sw_get_score_parameters",
+    "mi355sw_set_sequences", "mi355sw_unset_sequences", "mi355sw_align_partition",
+    "mi355sw_process_block", "mi355sw_match_last_column", "mi355sw_progress",
+    "mi355sw_processed_cells", "mi355sw_get_stats",
+    "mi355sw_stream_begin", "mi355sw_stream_feed_column", "mi355sw_stream_poll",
+    "mi355sw_stream_read_column", "mi355sw_stream_read_special_row", "mi355sw_stream_read_last_row",
+    "mi355sw_stream_abort", "mi355sw_stream_end", "mi355sw_stream_strip_scores",
+    "mi355sw_stream_device_first_column", "mi355sw_stream_device_last_column",
+    "mi355sw_stream_publish_first_column", "mi355sw_device_count", "mi355sw_device_info",
+]
+
+_lib = None
+
+
+def build_library(force=False):
+    """Compile csrc/ for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    src = os.path.join(HERE, "csrc")
+    deps = [os.path.join(src, f) for f in ("runtime.cpp", "sw_kernel.hip", "sw_kernel.h")] + [INCLUDE_PATH]
+    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
+        return LIB_PATH
+    subprocess.check_call(["make", "-C", src], stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+def load_library():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise AlignerError("libmi355sw.so is not built (run __graft_entry__.build()); there is no CPU fallback")
+    lib = C.CDLL(LIB_PATH)
+    H = C.c_void_p
+    lib.mi355sw_create.argtypes = [C.POINTER(Config), C.POINTER(H)]
+    lib.mi355sw_destroy.argtypes = [H]
+    lib.mi355sw_destroy.restype = None
+    lib.mi355sw_last_error.argtypes = [H]
+    lib.mi355sw_last_error.restype = C.c_char_p
+    lib.mi355sw_get_capabilities.argtypes = [H, C.POINTER(Capabilities)]
+    lib.mi355sw_get_score_parameters.argtypes = [H, C.POINTER(ScoreParams)]
+    lib.mi355sw_set_sequences.argtypes = [H, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]
+    lib.mi355sw_unset_sequences.argtypes = [H]
+    lib.mi355sw_align_partition.argtypes = [H, C.POINTER(Partition), C.POINTER(ManagerTable), C.c_void_p]
+    lib.mi355sw_process_block.argtypes = [H, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                          C.c_int32, C.POINTER(Score)]
+    lib.mi355sw_match_last_column.argtypes = [H, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.POINTER(MatchResult)]
+    lib.mi355sw_progress.argtypes = [H, C.c_char_p, C.c_size_t]
+    lib.mi355sw_processed_cells.argtypes = [H]
+    lib.mi355sw_processed_cells.restype = C.c_longlong
+    lib.mi355sw_get_stats.argtypes = [H, C.POINTER(Stats)]
+    lib.mi355sw_stream_begin.argtypes = [H, C.POINTER(Partition), C.POINTER(StreamParams)]
+    lib.mi355sw_stream_feed_column.argtypes = [H, C.c_int32, C.c_void_p, C.c_int32]
+    lib.mi355sw_stream_poll.argtypes = [H, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    lib.mi355sw_stream_read_column.argtypes = [H, C.c_int32, C.c_void_p, C.c_int32]
+    lib.mi355sw_stream_read_special_row.argtypes = [H, C.c_int32, C.POINTER(C.c_int32), C.c_void_p, C.c_int32, C.c_int32]
+    lib.mi355sw_stream_read_last_row.argtypes = [H, C.c_void_p, C.c_int32, C.c_int32]
+    lib.mi355sw_stream_abort.argtypes = [H]
+    lib.mi355sw_stream_end.argtypes = [H, C.POINTER(Score), C.POINTER(C.c_int32)]
+    lib.mi355sw_stream_strip_scores.argtypes = [H, C.c_void_p, C.c_int32]
+    lib.mi355sw_stream_device_first_column.argtypes = [H]
+    lib.mi355sw_stream_device_first_column.restype = C.c_void_p
+    lib.mi355sw_stream_device_last_column.argtypes = [H]
+    lib.mi355sw_stream_device_last_column.restype = C.c_void_p
+    lib.mi355sw_stream_publish_first_column.argtypes = [H, C.c_int32]
+    lib.mi355sw_device_info.argtypes = [C.c_int32, C.c_char_p, C.c_size_t, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                        C.POINTER(C.c_int64)]
+    _lib = lib
+    return lib
+
+
+def _as_u8(seq):
+    if isinstance(seq, (bytes, bytearray)):
+        return np.frombuffer(bytes(seq), dtype=np.uint8)
+    if isinstance(seq, str):
+        return np.frombuffer(seq.encode("ascii"), dtype=np.uint8)
+    return np.ascontiguousarray(seq, dtype=np.uint8)
+
+
+def _cells(a):
+    a = np.ascontiguousarray(a, dtype=np.int32)
+    assert a.ndim == 2 and a.shape[1] == 2
+    return a
+
+
+class MI355Aligner:
+    """Python mirror of the IAligner a MASA extension implements (M/libmasa/IAligner.hpp)."""
+
+    def __init__(self, device=-1, rows_per_lane=0, waves=0, flags=0, max_special_bytes=0):
+        self._lib = load_library()
+        self._h = C.c_void_p()
+        cfg = Config(device, rows_per_lane, waves, flags, max_special_bytes)
+        rc = self._lib.mi355sw_create(C.byref(cfg), C.byref(self._h))
+        if rc != 0:
+            self._h = C.c_void_p()
+            raise AlignerError("mi355sw_create failed: %s (the engine needs a gfx950 GPU; no CPU fallback)"
+                               % ERRORS.get(rc, rc))
+        self._seqs = None
+
+    # -- plumbing -------------------------------------------------------------------------
+    def _check(self, rc, what):
+        if rc != 0:
+            msg = self._lib.mi355sw_last_error(self._h)
+            raise AlignerError("%s: %s %s" % (what, ERRORS.get(rc, rc), msg.decode() if msg else ""))
+
+    def close(self):
+        if self._h:
+            self._lib.mi355sw_destroy(self._h)
+            self._h = C.c_void_p()
+
+    finalize = close  # IAligner::finalize
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- IAligner -------------------------------------------------------------------------
+    def getCapabilities(self):
+        c = Capabilities()
+        self._check(self._lib.mi355sw_get_capabilities(self._h, C.byref(c)), "getCapabilities")
+        return {k: getattr(c, k) for k, _ in Capabilities._fields_}
+
+    def getScoreParameters(self):
+        p = ScoreParams()
+        self._check(self._lib.mi355sw_get_score_parameters(self._h, C.byref(p)), "getScoreParameters")
+        return {"match": p.match, "mismatch": p.mismatch, "gap_open": p.gap_open, "gap_ext": p.gap_ext}
+
+    def setSequences(self, seq0, seq1, seq0_len=None, seq1_len=None):
+        s0, s1 = _as_u8(seq0), _as_u8(seq1)
+        l0 = len(s0) if seq0_len is None else seq0_len
+        l1 = len(s1) if seq1_len is None else seq1_len
+        self._check(self._lib.mi355sw_set_sequences(self._h, s0.ctypes.data, s1.ctypes.data, l0, l1), "setSequences")
+        self._seqs = (l0, l1)
+
+    def unsetSequences(self):
+        self._check(self._lib.mi355sw_unset_sequences(self._h), "unsetSequences")
+        self._seqs = None
+
+    def alignPartition(self, partition, manager):
+        """manager: object with the IManager methods (see manager.Stage1Manager)."""
+        table, keep = make_manager_table(manager)
+        self._check(self._lib.mi355sw_align_partition(self._h, C.byref(partition), C.byref(table), None),
+                    "alignPartition")
+        if getattr(manager, "_callback_error", None):
+            raise manager._callback_error
+        del keep
+
+    def processBlock(self, row, col, i0, j0, i1, j1, recurrence_type):
+        """AbstractBlockProcessor::processBlock: row (n,2), col (m+1,2) int32, updated in place."""
+        assert row.dtype == np.int32 and col.dtype == np.int32 and row.flags.c_contiguous and col.flags.c_contiguous
+        s = Score()
+        self._check(self._lib.mi355sw_process_block(self._h, row.ctypes.data, col.ctypes.data, i0, j0, i1, j1,
+                                                    recurrence_type, C.byref(s)), "processBlock")
+        return (s.i, s.j, s.score)
+
+    def matchLastColumn(self, buffer, base, goal_score):
+        b, a = _cells(buffer), _cells(base)
+        r = MatchResult()
+        self._check(self._lib.mi355sw_match_last_column(self._h, b.ctypes.data, a.ctypes.data, len(b), goal_score,
+                                                        C.byref(r)), "matchLastColumn")
+        return {"found": bool(r.found), "k": r.k, "score": r.score, "type": r.type}
+
+    def getProgressString(self):
+        buf = C.create_string_buffer(256)
+        self._lib.mi355sw_progress(self._h, buf, 256)
+        return buf.value.decode()
+
+    def getProcessedCells(self):
+        return self._lib.mi355sw_processed_cells(self._h)
+
+    def getStatistics(self):
+        s = Stats()
+        self._check(self._lib.mi355sw_get_stats(self._h, C.byref(s)), "getStatistics")
+        return {k: getattr(s, k) for k, _ in Stats._fields_}
+
+    # -- streaming form (column-band driver) ---------------------------------------------------
+    def streamBegin(self, partition, recurrence_type=SMITH_WATERMAN, first_row_init_type=INIT_WITH_ZEROES,
+                    first_row_start_offset=0, first_row=None, first_column_init_type=INIT_WITH_ZEROES,
+                    first_column_start_offset=0, stream_first_column=False, first_column=None,
+                    want_last_column=False, want_last_row=False, special_row_interval=0, track_best=True):
+        sp = StreamParams()
+        sp.recurrence_type = recurrence_type
+        sp.first_row_init_type, sp.first_row_start_offset = first_row_init_type, first_row_start_offset
+        keep = []
+        if first_row is not None:
+            a = _cells(first_row); keep.append(a); sp.first_row = a.ctypes.data
+        sp.first_column_init_type, sp.first_column_start_offset = first_column_init_type, first_column_start_offset
+        sp.stream_first_column = int(stream_first_column)
+        if first_column is not None:
+            a = _cells(first_column); keep.append(a); sp.first_column = a.ctypes.data
+        sp.want_last_column, sp.want_last_row = int(want_last_column), int(want_last_row)
+        sp.special_row_interval, sp.track_best = special_row_interval, int(track_best)
+        self._check(self._lib.mi355sw_stream_begin(self._h, C.byref(partition), C.byref(sp)), "streamBegin")
+        self._stream_part = partition
+
+    def streamFeedColumn(self, row, cells):
+        a = _cells(cells)
+        self._check(self._lib.mi355sw_stream_feed_column(self._h, row, a.ctypes.data, len(a)), "streamFeedColumn")
+
+    def streamPoll(self):
+        rows, fin = C.c_int32(), C.c_int32()
+        self._check(self._lib.mi355sw_stream_poll(self._h, C.byref(rows), C.byref(fin)), "streamPoll")
+        return rows.value, bool(fin.value)
+
+    def streamReadColumn(self, row, length):
+        out = np.empty((length, 2), dtype=np.int32)
+        self._check(self._lib.mi355sw_stream_read_column(self._h, row, out.ctypes.data, length), "streamReadColumn")
+        return out
+
+    def streamReadSpecialRow(self, k, col=0, length=None):
+        n = self._stream_part.getWidth()
+        length = n - col if length is None else length
+        out = np.empty((length, 2), dtype=np.int32)
+        dp = C.c_int32()
+        self._check(self._lib.mi355sw_stream_read_special_row(self._h, k, C.byref(dp), out.ctypes.data, col, length),
+                    "streamReadSpecialRow")
+        return dp.value, out
+
+    def streamReadLastRow(self, col=0, length=None):
+        n = self._stream_part.getWidth()
+        length = n - col if length is None else length
+        out = np.empty((length, 2), dtype=np.int32)
+        self._check(self._lib.mi355sw_stream_read_last_row(self._h, out.ctypes.data, col, length), "streamReadLastRow")
+        return out
+
+    def streamAbort(self):
+        self._check(self._lib.mi355sw_stream_abort(self._h), "streamAbort")
+
+    def streamEnd(self):
+        s, nsp = Score(), C.c_int32()
+        self._check(self._lib.mi355sw_stream_end(self._h, C.byref(s), C.byref(nsp)), "streamEnd")
+        return (s.i, s.j, s.score), nsp.value
+
+    def streamStripScores(self, max_count=1 << 22):
+        buf = np.empty((max_count, 3), dtype=np.int32)
+        cnt = self._lib.mi355sw_stream_strip_scores(self._h, buf.ctypes.data, max_count)
+        return buf[:cnt].copy()
+
+    def streamDeviceFirstColumn(self):
+        return self._lib.mi355sw_stream_device_first_column(self._h)
+
+    def streamDeviceLastColumn(self):
+        return self._lib.mi355sw_stream_device_last_column(self._h)
+
+    def streamPublishFirstColumn(self, rows):
+        self._check(self._lib.mi355sw_stream_publish_first_column(self._h, rows), "streamPublishFirstColumn")
+
+
+def make_manager_table(mgr):
+    """Wrap a Python IManager-like object into the C callback table (IManager.hpp:98-313)."""
+    mgr._callback_error = None
+
+    def guard(fn, default=0):
+        def w(*a):
+            try:
+                r = fn(*a)
+                return default if r is None else r
+            except BaseException as e:  # never let an exception cross the C boundary
+                if mgr._callback_error is None:
+                    mgr._callback_error = e
+                return default
+        return w
+
+    def recv(method):
+        def f(_u, buf, length):
+            arr = np.ctypeslib.as_array(C.cast(buf, C.POINTER(C.c_int32)), shape=(length, 2))
+            method(arr, length)
+        return guard(f, None)
+
+    def disp(method):
+        def f(_u, pos, buf, length):
+            arr = np.ctypeslib.as_array(C.cast(buf, C.POINTER(C.c_int32)), shape=(length, 2))
+            method(pos, arr, length)
+        return guard(f, None)
+
+    def superp(_u, out):
+        p = mgr.getSuperPartition()
+        out[0].i0, out[0].j0, out[0].i1, out[0].j1 = p.i0, p.j0, p.i1, p.j1
+
+    def score(_u, s, bx, by):
+        mgr.dispatchScore((s.i, s.j, s.score), bx, by)
+
+    keep = dict(
+        get_recurrence_type=CB_INT(guard(lambda u: mgr.getRecurrenceType())),
+        get_special_row_interval=CB_INT(guard(lambda u: mgr.getSpecialRowInterval())),
+        get_first_column_init_type=CB_INT(guard(lambda u: mgr.getFirstColumnInitType())),
+        get_first_row_init_type=CB_INT(guard(lambda u: mgr.getFirstRowInitType())),
+        get_super_partition=CB_PART(guard(superp, None)),
+        receive_first_row=CB_RECV(recv(mgr.receiveFirstRow)),
+        receive_first_column=CB_RECV(recv(mgr.receiveFirstColumn)),
+        dispatch_column=CB_DISP(disp(mgr.dispatchColumn)),
+        dispatch_row=CB_DISP(disp(mgr.dispatchRow)),
+        dispatch_score=CB_SCORE(guard(score, None)),
+        must_continue=CB_INT(guard(lambda u: int(mgr.mustContinue()), 0)),
+        must_dispatch_last_cell=CB_INT(guard(lambda u: int(mgr.mustDispatchLastCell()))),
+        must_dispatch_last_row=CB_INT(guard(lambda u: int(mgr.mustDispatchLastRow()))),
+        must_dispatch_last_column=CB_INT(guard(lambda u: int(mgr.mustDispatchLastColumn()))),
+        must_dispatch_special_rows=CB_INT(guard(lambda u: int(mgr.mustDispatchSpecialRows()))),
+        must_dispatch_scores=CB_INT(guard(lambda u: int(mgr.mustDispatchScores()))),
+        must_prune_blocks=CB_INT(guard(lambda u: int(mgr.mustPruneBlocks()))),
+    )
+    table = ManagerTable(**keep)
+    return table, keep
