@@ -385,9 +385,10 @@ int mi355sw_stream_begin(mi355sw_handle* h, const mi355sw_partition* part, const
     a.abort_flag = ctrl + 16;
     a.error_flag = ctrl + 32;
     a.strips_done_dev = ctrl + 48;
-    a.strips_done_host = h->h_pinned + 0;
+    a.strips_done_host = getenv("MI355SW_NOHOST") ? nullptr : h->h_pinned + 0;
     a.first_col_ready = (need_first_col && p->stream_first_column) ? h->h_pinned + 16 : nullptr;
     a.strip_best = (int4*) h->d_strip_best.p;
+    a.dbg = getenv("MI355SW_DEBUG") ? ctrl + 56 : nullptr;
 
     h->stats = mi355sw_stats{};
     h->stats.cells = (int64_t) m * n;
@@ -747,6 +748,15 @@ int mi355sw_match_last_column(mi355sw_handle* h, const mi355sw_cell* buffer, con
 int mi355sw_progress(mi355sw_handle* h, char* buf, size_t len) {
     if (!h || !buf || !len) return MI355SW_EINVAL;
     int done = h->h_pinned ? __atomic_load_n(&h->h_pinned[0], __ATOMIC_RELAXED) : 0;
+    if (getenv("MI355SW_DEBUG") && h->d_ctrl.p && h->copy) {
+        int ctrl[64];
+        if (hipMemcpyAsync(ctrl, h->d_ctrl.p, sizeof(ctrl), hipMemcpyDeviceToHost, h->copy) == hipSuccess &&
+            hipStreamSynchronize(h->copy) == hipSuccess) {
+            snprintf(buf, len, "PROGRESS: %d/%d strips ticket=%d abort=%d err=%d done_dev=%d dbg=[%d %d %d %d | %d %d %d]", done,
+                     h->prog_total.load(), ctrl[0], ctrl[16], ctrl[32], ctrl[48], ctrl[56], ctrl[57], ctrl[58], ctrl[59], ctrl[60], ctrl[61], ctrl[62]);
+            return MI355SW_OK;
+        }
+    }
     snprintf(buf, len, "PROGRESS: %d/%d strips", done, h->prog_total.load());
     return MI355SW_OK;
 }

@@ -39,6 +39,7 @@ struct KernelArgs {
     int* strips_done_dev;        // device counter, ordered: value s means strips [0,s) complete
     int* strips_done_host;       // pinned host mirror (system scope)
     int4* strip_best;            // per strip {score, i, j, valid}
+    int* dbg;                    // optional debug words (nullptr in production)
 };
 
 hipError_t launch_strip_kernel(const KernelArgs& a, int rows_per_lane, int grid, hipStream_t stream,

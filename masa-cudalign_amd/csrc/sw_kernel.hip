@@ -30,6 +30,8 @@
 
 namespace mi355sw {
 
+#define DBG(k, v) do { if (a.dbg != nullptr && lane == 0) st_agent(&a.dbg[k], (v)); } while (0)
+
 #define GAP_FIRST 5   // DNA_GAP_OPEN + DNA_GAP_EXT (CUDAligner.hpp:92-98)
 #define GAP_EXT 2
 #define NEG_INF (-999999999)   // libmasaTypes.hpp:46
@@ -61,6 +63,14 @@ __device__ __forceinline__ void st_agent2(int2* p, int2 v) {
     __hip_atomic_store((unsigned long long*) p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// wave-uniform polls: the loaded word is the same in every lane; readfirstlane tells the compiler so
+// (scalar branches instead of EXEC-masked loops)
+__device__ __forceinline__ int poll_agent(const int* p) {
+    return __builtin_amdgcn_readfirstlane(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ int poll_sys(const int* p) {
+    return __builtin_amdgcn_readfirstlane(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+}
 __device__ __forceinline__ int ld_sys(const int* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
@@ -158,205 +168,222 @@ __device__ __forceinline__ void wave_step(LaneState<R>& st, WaveLds* lds, const 
 }
 
 template <int R, bool SW, bool PROFILE, bool TRACK>
+__device__ __attribute__((noinline)) void process_strip(const KernelArgs& a, const int s, WaveLds* lds, const int lane) {
+    const int n = a.n;
+    const int SH = 64 * R;
+    const int nchunks = (n + 63 + CHUNK - 1) / CHUNK;
+    const int row0 = a.strip_row0 + s * SH;          // first DP row of this strip (0-based)
+    const int lrow0 = row0 + lane * R;                // first row of this lane
+    const int rows_left = a.m - lrow0;
+    const int nvalid = rows_left < 0 ? 0 : (rows_left > R ? R : rows_left);
+    const int* prog_in = &a.progress[s];              // progress of the strip above
+    int* prog_out = &a.progress[s + 1];
+
+    // which (lane,row) is the row handed to the next strip / flushed as special row
+    int emit_lane = 63, emit_row = R - 1;
+    const bool ragged = (row0 + SH > a.m);
+    if (ragged) {
+        const int last = a.m - 1 - row0;              // last valid row inside the strip
+        emit_lane = last / R;
+        emit_row = last - emit_lane * R;
+    }
+    const bool last_strip = (row0 + SH >= a.m);
+    int2* special = nullptr;
+    if (a.special_interval_strips > 0 && a.special_rows != nullptr) {
+        const int sg = a.strip_index0 + s + 1;       // strips completed once this one ends
+        if (sg % a.special_interval_strips == 0 && (long long) sg * SH < a.m)
+            special = a.special_rows + (long long) (sg / a.special_interval_strips - 1) * a.special_pitch;
+    }
+    int2* lastrow = (last_strip && a.last_row != nullptr) ? a.last_row : nullptr;
+
+    // ---- per-lane state from the first column (InitialCellsReader semantics on device) ----
+    if (a.first_col != nullptr && a.first_col_ready != nullptr) {
+        int need = row0 + SH;                         // rows [0,need) of the first column
+        if (need > a.m) need = a.m;
+        int spins = 0;
+        while (poll_sys(a.first_col_ready) < need && poll_agent(a.abort_flag) == 0 && spins < (1 << 26)) {
+            __builtin_amdgcn_s_sleep(32);
+            spins++;
+        }
+        if (spins >= (1 << 26) && lane == 0) atomicExch(a.error_flag, 2);
+    }
+    LaneState<R> st;
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        int h = 0, e = NEG_INF;
+        if (a.first_col != nullptr) {
+            const int g = lrow0 + r;
+            if (g < a.m) {
+                const int2 c = ld_sys2(&a.first_col[g + 1]);
+                h = c.x; e = c.y;
+            }
+        }
+        st.tl[r] = h - GAP_FIRST;
+        st.e[r] = e;
+        const int g = lrow0 + r;
+        const int c0 = (g < a.m) ? (int) a.seq0[g] : a.pad_code;
+        if (PROFILE) {
+            // nibble k = score(c0, code k) + 5 : 6 on match, 2 otherwise; pad/foreign codes never match
+            u32 p = 0x22222222u;
+            if (c0 < a.n_match_codes) p += (4u << (4 * c0));
+            st.prof[r] = (int) p;
+        } else {
+            st.prof[r] = c0;
+        }
+    }
+    {
+        int hd = 0;
+        if (a.first_col != nullptr && lrow0 <= a.m) hd = ld_sys2(&a.first_col[lrow0]).x;
+        st.tup_prev = hd - GAP_FIRST;
+    }
+    st.tbot = NEG_INF; st.fbot = NEG_INF;
+    st.best_t = NEG_INF; st.best_r = R; st.best_j = -1;
+
+    DBG(1, 1);
+    // ---- sweep the strip ----
+    for (int c = 0; c < nchunks; c++) {
+        const int col0 = c * CHUNK;
+        DBG(2, c); DBG(3, 10);
+        // (1) input chunk: wait for the strip above, then stage bus + seq1 codes into LDS
+        {
+            int need = col0 + CHUNK;
+            if (need > n) need = n;
+            if (col0 < n) {
+                int spins = 0;
+                while (poll_agent(prog_in) < need && spins < (1 << 24)) {
+                    __builtin_amdgcn_s_sleep(2);
+                    spins++;
+                }
+                if (spins >= (1 << 24) && lane == 0) atomicExch(a.error_flag, 1);
+            }
+            const int col = col0 + lane;
+            int2 hf = make_int2(0, NEG_INF);
+            unsigned char code = 0;
+            if (col < n) {
+                hf = ld_agent2(&a.bus[col]);
+                code = a.seq1[col];
+            }
+            // shift the seq1 window: [64,128) -> [0,64), then the new chunk
+            const unsigned char prev = lds->c1[CHUNK + lane];
+            lds->c1[lane] = prev;
+            lds->c1[CHUNK + lane] = code;
+            lds->in_tf[lane] = make_int2(hf.x - GAP_FIRST, hf.y);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+        DBG(3, 20);
+        // (2) 64 systolic steps
+        const int jl = col0 - lane;
+        const bool masked = (c == 0) || (col0 + CHUNK - 1 >= n);
+        int2 feed = lds->in_tf[0];
+        int c1 = lds->c1[CHUNK - lane];
+        if (ragged) {
+#pragma unroll 2
+            for (int u = 0; u < CHUNK; u++)
+                wave_step<R, SW, PROFILE, true, TRACK, true>(st, lds, u, lane, jl, n, nvalid, emit_lane, emit_row, feed, c1);
+        } else if (masked) {
+#pragma unroll 2
+            for (int u = 0; u < CHUNK; u++)
+                wave_step<R, SW, PROFILE, true, TRACK, false>(st, lds, u, lane, jl, n, nvalid, 63, R - 1, feed, c1);
+        } else {
+#pragma unroll 4
+            for (int u = 0; u < CHUNK; u++)
+                wave_step<R, SW, PROFILE, false, TRACK, false>(st, lds, u, lane, jl, n, nvalid, 63, R - 1, feed, c1);
+        }
+        DBG(3, 30);
+        // (3) output chunk: columns col0-emit_lane .. col0-emit_lane+63
+        {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const int2 tf = lds->out_tf[lane];
+            const int col = col0 - emit_lane + lane;
+            if (col >= 0 && col < n) {
+                const int2 hf = make_int2(tf.x + GAP_FIRST, tf.y);
+                st_agent2(&a.bus[col], hf);
+                if (special != nullptr) special[col] = hf;
+                if (lastrow != nullptr) lastrow[col] = hf;
+            }
+            // every store of this wave must have left before the flag (R1: drain, then flag)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            int done = col0 - emit_lane + CHUNK;
+            if (done > n) done = n;
+            if (done < 0) done = 0;
+            if (lane == 0) st_agent(prog_out, done);
+        }
+    }
+
+    DBG(3, 40);
+    // ---- strip epilogue: last column, best score ----
+    if (a.last_col != nullptr) {
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const int g = lrow0 + r;
+            if (g < a.m) a.last_col[g + 1] = make_int2(st.tl[r] + GAP_FIRST, st.e[r]);
+        }
+    }
+    if (TRACK) {
+        // canonical reduction over lanes: max t, then min row, then min j
+        lds->red[lane] = st.best_t;
+        lds->red[64 + lane] = (st.best_j >= 0) ? (lrow0 + st.best_r) : 0x7fffffff;
+        lds->red[128 + lane] = st.best_j;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (lane == 0) {
+            int bt = NEG_INF, bi = 0x7fffffff, bj = -1;
+            for (int k = 0; k < 64; k++) {
+                const int t = lds->red[k], i = lds->red[64 + k], j = lds->red[128 + k];
+                if (j >= 0 && (t > bt || (t == bt && (i < bi || (i == bi && j < bj))))) {
+                    bt = t; bi = i; bj = j;
+                }
+            }
+            int4 rec;
+            rec.x = (bj >= 0) ? bt + GAP_FIRST : NEG_INF;
+            rec.y = bi; rec.z = bj; rec.w = 1;
+            a.strip_best[s] = rec;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+template <int R, bool SW, bool PROFILE, bool TRACK>
 __global__ void __launch_bounds__(64) sw_strip_kernel(KernelArgs a) {
     __shared__ WaveLds lds_store;
     WaveLds* lds = &lds_store;
     const int lane = threadIdx.x;
     const int n = a.n;
-    const int SH = 64 * R;
-    const int nchunks = (n + 63 + CHUNK - 1) / CHUNK;
 
     for (;;) {
         // ---- claim the next strip (ordered tickets => forward progress) ----
         int s = 0;
         if (lane == 0) s = atomicAdd(a.ticket, 1);
         s = __builtin_amdgcn_readfirstlane(s);
+        DBG(0, 100 + s);
         if (s >= a.num_strips) break;
-        if (ld_agent(a.abort_flag) != 0) {
+        if (poll_agent(a.abort_flag) != 0) {
             // publish completion so that followers do not spin forever
             if (lane == 0) st_agent(&a.progress[s + 1], n);
-            continue;
+        } else {
+            process_strip<R, SW, PROFILE, TRACK>(a, s, lds, lane);
         }
-        const int row0 = a.strip_row0 + s * SH;          // first DP row of this strip (0-based)
-        const int lrow0 = row0 + lane * R;                // first row of this lane
-        const int rows_left = a.m - lrow0;
-        const int nvalid = rows_left < 0 ? 0 : (rows_left > R ? R : rows_left);
-        const int* prog_in = &a.progress[s];              // progress of the strip above
-        int* prog_out = &a.progress[s + 1];
-
-        // which (lane,row) is the row handed to the next strip / flushed as special row
-        int emit_lane = 63, emit_row = R - 1;
-        const bool ragged = (row0 + SH > a.m);
-        if (ragged) {
-            const int last = a.m - 1 - row0;              // last valid row inside the strip
-            emit_lane = last / R;
-            emit_row = last - emit_lane * R;
-        }
-        const bool last_strip = (row0 + SH >= a.m);
-        int2* special = nullptr;
-        if (a.special_interval_strips > 0 && a.special_rows != nullptr) {
-            const int sg = a.strip_index0 + s + 1;       // strips completed once this one ends
-            if (sg % a.special_interval_strips == 0 && (long long) sg * SH < a.m)
-                special = a.special_rows + (long long) (sg / a.special_interval_strips - 1) * a.special_pitch;
-        }
-        int2* lastrow = (last_strip && a.last_row != nullptr) ? a.last_row : nullptr;
-
-        // ---- per-lane state from the first column (InitialCellsReader semantics on device) ----
-        if (a.first_col != nullptr && a.first_col_ready != nullptr) {
-            int need = row0 + SH;                         // rows [0,need) of the first column
-            if (need > a.m) need = a.m;
-            int spins = 0;
-            while (ld_sys(a.first_col_ready) < need) {
-                __builtin_amdgcn_s_sleep(32);
-                if (ld_agent(a.abort_flag) != 0) break;
-                if (++spins > (1 << 28)) { if (lane == 0) atomicExch(a.error_flag, 2); break; }
-            }
-        }
-        LaneState<R> st;
-#pragma unroll
-        for (int r = 0; r < R; r++) {
-            int h = 0, e = NEG_INF;
-            if (a.first_col != nullptr) {
-                const int g = lrow0 + r;
-                if (g < a.m) {
-                    const int2 c = ld_sys2(&a.first_col[g + 1]);
-                    h = c.x; e = c.y;
-                }
-            }
-            st.tl[r] = h - GAP_FIRST;
-            st.e[r] = e;
-            const int g = lrow0 + r;
-            const int c0 = (g < a.m) ? (int) a.seq0[g] : a.pad_code;
-            if (PROFILE) {
-                // nibble k = score(c0, code k) + 5 : 6 on match, 2 otherwise; pad/foreign codes never match
-                u32 p = 0x22222222u;
-                if (c0 < a.n_match_codes) p += (4u << (4 * c0));
-                st.prof[r] = (int) p;
-            } else {
-                st.prof[r] = c0;
-            }
-        }
-        {
-            int hd = 0;
-            if (a.first_col != nullptr && lrow0 <= a.m) hd = ld_sys2(&a.first_col[lrow0]).x;
-            st.tup_prev = hd - GAP_FIRST;
-        }
-        st.tbot = NEG_INF; st.fbot = NEG_INF;
-        st.best_t = NEG_INF; st.best_r = R; st.best_j = -1;
-
-        // ---- sweep the strip ----
-        for (int c = 0; c < nchunks; c++) {
-            const int col0 = c * CHUNK;
-            // (1) input chunk: wait for the strip above, then stage bus + seq1 codes into LDS
-            {
-                int need = col0 + CHUNK;
-                if (need > n) need = n;
-                if (col0 < n) {
-                    int spins = 0;
-                    while (ld_agent(prog_in) < need) {
-                        __builtin_amdgcn_s_sleep(2);
-                        if (++spins > (1 << 26)) { if (lane == 0) atomicExch(a.error_flag, 1); break; }
-                    }
-                }
-                const int col = col0 + lane;
-                int2 hf = make_int2(0, NEG_INF);
-                unsigned char code = 0;
-                if (col < n) {
-                    hf = ld_agent2(&a.bus[col]);
-                    code = a.seq1[col];
-                }
-                // shift the seq1 window: [64,128) -> [0,64), then the new chunk
-                const unsigned char prev = lds->c1[CHUNK + lane];
-                lds->c1[lane] = prev;
-                lds->c1[CHUNK + lane] = code;
-                lds->in_tf[lane] = make_int2(hf.x - GAP_FIRST, hf.y);
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            }
-            // (2) 64 systolic steps
-            const int jl = col0 - lane;
-            const bool masked = (c == 0) || (col0 + CHUNK - 1 >= n);
-            int2 feed = lds->in_tf[0];
-            int c1 = lds->c1[CHUNK - lane];
-            if (ragged) {
-#pragma unroll 2
-                for (int u = 0; u < CHUNK; u++)
-                    wave_step<R, SW, PROFILE, true, TRACK, true>(st, lds, u, lane, jl, n, nvalid, emit_lane, emit_row, feed, c1);
-            } else if (masked) {
-#pragma unroll 2
-                for (int u = 0; u < CHUNK; u++)
-                    wave_step<R, SW, PROFILE, true, TRACK, false>(st, lds, u, lane, jl, n, nvalid, 63, R - 1, feed, c1);
-            } else {
-#pragma unroll 4
-                for (int u = 0; u < CHUNK; u++)
-                    wave_step<R, SW, PROFILE, false, TRACK, false>(st, lds, u, lane, jl, n, nvalid, 63, R - 1, feed, c1);
-            }
-            // (3) output chunk: columns col0-emit_lane .. col0-emit_lane+63
-            {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                const int2 tf = lds->out_tf[lane];
-                const int col = col0 - emit_lane + lane;
-                if (col >= 0 && col < n) {
-                    const int2 hf = make_int2(tf.x + GAP_FIRST, tf.y);
-                    st_agent2(&a.bus[col], hf);
-                    if (special != nullptr) special[col] = hf;
-                    if (lastrow != nullptr) lastrow[col] = hf;
-                }
-                // every store of this wave must have left before the flag (R1: drain, then flag)
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                int done = col0 - emit_lane + CHUNK;
-                if (done > n) done = n;
-                if (done < 0) done = 0;
-                if (lane == 0) st_agent(prog_out, done);
-            }
-        }
-
-        // ---- strip epilogue: last column, best score ----
-        if (a.last_col != nullptr) {
-#pragma unroll
-            for (int r = 0; r < R; r++) {
-                const int g = lrow0 + r;
-                if (g < a.m) a.last_col[g + 1] = make_int2(st.tl[r] + GAP_FIRST, st.e[r]);
-            }
-        }
-        if (TRACK) {
-            // canonical reduction over lanes: max t, then min row, then min j
-            lds->red[lane] = st.best_t;
-            lds->red[64 + lane] = (st.best_j >= 0) ? (lrow0 + st.best_r) : 0x7fffffff;
-            lds->red[128 + lane] = st.best_j;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            if (lane == 0) {
-                int bt = NEG_INF, bi = 0x7fffffff, bj = -1;
-                for (int k = 0; k < 64; k++) {
-                    const int t = lds->red[k], i = lds->red[64 + k], j = lds->red[128 + k];
-                    if (j >= 0 && (t > bt || (t == bt && (i < bi || (i == bi && j < bj))))) {
-                        bt = t; bi = i; bj = j;
-                    }
-                }
-                int4 rec;
-                rec.x = (bj >= 0) ? bt + GAP_FIRST : NEG_INF;
-                rec.y = bi; rec.z = bj; rec.w = 1;
-                a.strip_best[s] = rec;
-            }
-            __builtin_amdgcn_wave_barrier();
-        }
+        DBG(3, 50);
         // ---- ordered completion: strips_done == s+1 means strips 0..s are complete and their
         //      last-column / special-row / best records are visible to the host (system scope) ----
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+        int spins = 0;
+        while (poll_agent(a.strips_done_dev) != s && spins < (1 << 24)) {
+            __builtin_amdgcn_s_sleep(8);
+            spins++;
+        }
         if (lane == 0) {
-            int spins = 0;
-            while (ld_agent(a.strips_done_dev) != s) {
-                __builtin_amdgcn_s_sleep(8);
-                if (++spins > (1 << 26)) { atomicExch(a.error_flag, 3); break; }
-            }
-            __hip_atomic_store(a.strips_done_host, s + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (spins >= (1 << 24)) atomicExch(a.error_flag, 3);
+            if (a.strips_done_host != nullptr)
+                __hip_atomic_store(a.strips_done_host, s + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
             st_agent(a.strips_done_dev, s + 1);
         }
+        DBG(3, 54);
     }
 }
 
