@@ -190,6 +190,10 @@ int mi355sw_stream_strip_scores(mi355sw_handle* h, mi355sw_score* out, int32_t m
  * caller (RCCL send/recv on these addresses); NULL if not allocated */
 void* mi355sw_stream_device_first_column(mi355sw_handle* h);
 void* mi355sw_stream_device_last_column(mi355sw_handle* h);
+/* device-pointer variants of feed/read (D2D on the engine's copy stream): `dev_cells` is a device
+ * address on the engine's GPU, e.g. the landing buffer of an RCCL recv / the source of an RCCL send */
+int mi355sw_stream_feed_column_device(mi355sw_handle* h, int32_t row, const void* dev_cells, int32_t len);
+int mi355sw_stream_read_column_device(mi355sw_handle* h, int32_t row, void* dev_cells, int32_t len);
 /* tell the engine that rows [0,rows) of the device first-column buffer are now valid (after a
  * device-side transfer the caller performed itself) */
 int mi355sw_stream_publish_first_column(mi355sw_handle* h, int32_t rows);

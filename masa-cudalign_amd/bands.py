@@ -1,0 +1,147 @@
+"""Column-band (multi-GPU) Stage-1 driver: one process per GPU, band g owns columns
+[n*W_g/sum(W), n*W_{g+1}/sum(W)) of seq1 and every row of seq0; band g streams its LAST column
+(H,E per row) to band g+1, which consumes it as its FIRST column (INIT_WITH_CUSTOM_DATA).
+
+Replaces the reference's --fork/--split chain (M/libmasa/libmasa.cpp:497-642): forked processes
+joined by TCP sockets carrying cell_t (M/common/io/SocketCells{Reader,Writer}.cpp), best score
+relayed through AlignerPool signal files (M/stage1/sw_stage1.cpp:421-464).  Here the boundary
+column goes point-to-point through torch.distributed (backend nccl == RCCL over xGMI on the GPU
+box, gloo in the CPU tests) in row segments while the strip kernel keeps running, and the best
+score is an all_gather of one (score,i,j) triple reduced with BestScoreList's order.
+
+The compute engine is injected (`engine_factory`) so that the N>1 plumbing can be exercised on CPU
+with a stand-in; the product engine is MI355Aligner (HIP, no CPU fallback).
+"""
+import threading
+import time
+
+import numpy as np
+
+from .engine import INF, SMITH_WATERMAN, INIT_WITH_ZEROES, INIT_WITH_CUSTOM_DATA, Partition
+
+
+def band_limits(n, weights):
+    """split_sequences, libmasa.cpp:497-535: band g = (n*P[g]/sum, n*P[g+1]/sum] in 1-based trim
+    coordinates, i.e. 0-based half-open [n*P[g]//sum, n*P[g+1]//sum)."""
+    tot = int(sum(weights))
+    acc = [0]
+    for w in weights:
+        acc.append(acc[-1] + int(w))
+    return [(n * acc[g]) // tot for g in range(len(weights) + 1)]
+
+
+def canonical_best(cands):
+    """BestScoreList order (M/common/BestScoreList.hpp:30-38): score desc, i asc, j asc."""
+    best = (-1, -1, -INF)
+    for (i, j, s) in cands:
+        if j < 0 and i < 0:
+            continue
+        if s > best[2] or (s == best[2] and (i < best[0] or (i == best[0] and j < best[1]))):
+            best = (int(i), int(j), int(s))
+    return best
+
+
+class BandRunner:
+    """Runs one band of the chain on this rank.  `dist` is torch.distributed (already initialised)
+    or None for a single band.  All ranks must call run() with the same m, n, weights, segment."""
+
+    def __init__(self, engine, dist=None, rank=0, world=1, device=None, segment_rows=1 << 16):
+        self.engine, self.dist, self.rank, self.world = engine, dist, rank, world
+        self.device = device
+        self.segment_rows = segment_rows
+
+    def _tensor(self, rows):
+        import torch
+        return torch.empty((rows, 2), dtype=torch.int32, device=self.device if self.device is not None else "cpu")
+
+    def run(self, m, j0, j1, recurrence=SMITH_WATERMAN, track_best=True, first_row_init_type=INIT_WITH_ZEROES,
+            first_col_init_type=INIT_WITH_ZEROES, poll_sleep=0.0005):
+        """seq1 of the engine must already hold the whole horizontal sequence (or at least [j0,j1))."""
+        eng, dist = self.engine, self.dist
+        first, last = self.rank == 0, self.rank == self.world - 1
+        part = Partition(0, j0, m, j1)
+        seg = self.segment_rows
+        nseg = (m + seg - 1) // seg
+        kw = dict(recurrence_type=recurrence, track_best=track_best,
+                  first_row_init_type=first_row_init_type, first_row_start_offset=j0,
+                  want_last_column=not last)
+        if first:
+            kw.update(first_column_init_type=first_col_init_type)
+        else:
+            # corner cell = first-row cell at column j0-1+1 ... (H of DP cell (0, j0)): zero-initialised
+            # rows give (0,-INF); custom rows are handled by the caller feeding row 0 of the stream.
+            corner = np.array([[0, -INF]], dtype=np.int32)
+            if first_row_init_type != INIT_WITH_ZEROES:
+                open_ = 3 if first_row_init_type == 1 else 0
+                corner[0, 0] = -2 * j0 - open_ if j0 > 0 else 0
+            kw.update(first_column_init_type=INIT_WITH_CUSTOM_DATA, stream_first_column=True, first_column=corner)
+        eng.streamBegin(part, **kw)
+
+        use_dev = self.device is not None and str(self.device).startswith("cuda")
+        lock = threading.Lock()          # the engine handle is driven by one thread at a time
+        errors = []
+
+        def receiver():
+            # inbound boundary column: blocking recv of row segments from the left neighbour
+            try:
+                for q in range(nseg):
+                    r0 = q * seg
+                    ln = min(seg, m - r0)
+                    buf = self._tensor(ln)
+                    dist.recv(buf, src=self.rank - 1)
+                    with lock:
+                        if use_dev:
+                            eng.streamFeedColumnDevice(r0, buf.data_ptr(), ln)
+                        else:
+                            eng.streamFeedColumn(r0, buf.numpy())
+            except BaseException as e:     # surfaced by the main loop
+                errors.append(e)
+
+        rx = None
+        if not first:
+            rx = threading.Thread(target=receiver, daemon=True)
+            rx.start()
+        send_q = 0
+        while True:
+            if errors:
+                with lock:
+                    eng.streamAbort()
+                    eng.streamEnd()
+                raise errors[0]
+            with lock:
+                rows_done, fin = eng.streamPoll()
+            progressed = False
+            # outbound boundary column: every complete segment goes to the right neighbour
+            while not last and send_q < nseg:
+                r0 = send_q * seg
+                ln = min(seg, m - r0)
+                if rows_done < r0 + ln:
+                    break
+                buf = self._tensor(ln)
+                with lock:
+                    if use_dev:
+                        eng.streamReadColumnDevice(r0, buf.data_ptr(), ln)
+                    else:
+                        import torch
+                        buf.copy_(torch.from_numpy(eng.streamReadColumn(r0, ln)))
+                dist.send(buf, dst=self.rank + 1)
+                send_q += 1
+                progressed = True
+            if fin and (last or send_q >= nseg):
+                break
+            if not progressed:
+                time.sleep(poll_sleep)
+        if rx is not None:
+            rx.join()
+        best, _ = eng.streamEnd()
+        return best
+
+    def reduce_best(self, best):
+        """global best = canonical max over bands (reference: relay through AlignerPool files)."""
+        if self.dist is None or self.world == 1:
+            return best
+        import torch
+        t = torch.tensor(list(best), dtype=torch.int64, device=self.device if self.device is not None else "cpu")
+        out = [torch.empty_like(t) for _ in range(self.world)]
+        self.dist.all_gather(out, t)
+        return canonical_best([tuple(int(x) for x in o.tolist()) for o in out])

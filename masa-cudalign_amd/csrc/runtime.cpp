@@ -421,6 +421,27 @@ int mi355sw_stream_feed_column(mi355sw_handle* h, int32_t row, const mi355sw_cel
     return MI355SW_OK;
 }
 
+int mi355sw_stream_feed_column_device(mi355sw_handle* h, int32_t row, const void* dev_cells, int32_t len) {
+    if (!h || !h->active) return MI355SW_ESTATE;
+    if (row != h->fed_rows || len < 0 || row + len > h->m) FAIL(h, MI355SW_EINVAL, "feed_column_device out of order");
+    if (len == 0) return MI355SW_OK;
+    HIPCHK(h, hipMemcpyAsync((int2*) h->d_first_col.p + 1 + row, dev_cells, sizeof(int2) * (size_t) len,
+                             hipMemcpyDeviceToDevice, h->copy));
+    HIPCHK(h, hipStreamSynchronize(h->copy));
+    h->fed_rows += len;
+    __atomic_store_n(&h->h_pinned[16], h->fed_rows, __ATOMIC_RELEASE);
+    return MI355SW_OK;
+}
+
+int mi355sw_stream_read_column_device(mi355sw_handle* h, int32_t row, void* dev_cells, int32_t len) {
+    if (!h || !h->active || !h->sp.want_last_column) return MI355SW_ESTATE;
+    if (row < 0 || len < 0 || row + len > h->m) FAIL(h, MI355SW_EINVAL, "read_column_device range");
+    HIPCHK(h, hipMemcpyAsync(dev_cells, (int2*) h->d_last_col.p + 1 + row, sizeof(int2) * (size_t) len,
+                             hipMemcpyDeviceToDevice, h->copy));
+    HIPCHK(h, hipStreamSynchronize(h->copy));
+    return MI355SW_OK;
+}
+
 int mi355sw_stream_publish_first_column(mi355sw_handle* h, int32_t rows) {
     if (!h || !h->active) return MI355SW_ESTATE;
     if (rows < h->fed_rows || rows > h->m) FAIL(h, MI355SW_EINVAL, "publish_first_column out of range");

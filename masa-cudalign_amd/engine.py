@@ -121,7 +121,8 @@ ABI_SYMBOLS = [
     "mi355sw_stream_read_column", "mi355sw_stream_read_special_row", "mi355sw_stream_read_last_row",
     "mi355sw_stream_abort", "mi355sw_stream_end", "mi355sw_stream_strip_scores",
     "mi355sw_stream_device_first_column", "mi355sw_stream_device_last_column",
-    "mi355sw_stream_publish_first_column", "mi355sw_device_count", "mi355sw_device_info",
+    "mi355sw_stream_publish_first_column", "mi355sw_stream_feed_column_device",
+    "mi355sw_stream_read_column_device", "mi355sw_device_count", "mi355sw_device_info",
 ]
 
 _lib = None
@@ -176,6 +177,8 @@ def load_library():
     lib.mi355sw_stream_device_last_column.argtypes = [H]
     lib.mi355sw_stream_device_last_column.restype = C.c_void_p
     lib.mi355sw_stream_publish_first_column.argtypes = [H, C.c_int32]
+    lib.mi355sw_stream_feed_column_device.argtypes = [H, C.c_int32, C.c_void_p, C.c_int32]
+    lib.mi355sw_stream_read_column_device.argtypes = [H, C.c_int32, C.c_void_p, C.c_int32]
     lib.mi355sw_device_info.argtypes = [C.c_int32, C.c_char_p, C.c_size_t, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                         C.POINTER(C.c_int64)]
     _lib = lib
@@ -311,6 +314,12 @@ class MI355Aligner:
     def streamFeedColumn(self, row, cells):
         a = _cells(cells)
         self._check(self._lib.mi355sw_stream_feed_column(self._h, row, a.ctypes.data, len(a)), "streamFeedColumn")
+
+    def streamFeedColumnDevice(self, row, dev_ptr, length):
+        self._check(self._lib.mi355sw_stream_feed_column_device(self._h, row, dev_ptr, length), "streamFeedColumnDevice")
+
+    def streamReadColumnDevice(self, row, dev_ptr, length):
+        self._check(self._lib.mi355sw_stream_read_column_device(self._h, row, dev_ptr, length), "streamReadColumnDevice")
 
     def streamPoll(self):
         rows, fin = C.c_int32(), C.c_int32()

@@ -14,7 +14,7 @@ REF_DRIVER = os.path.join(HERE, "_ref", "ref_driver")
 INF = 999999999
 NEEDLEMAN_WUNSCH, SMITH_WATERMAN = 0, 1
 INIT_WITH_ZEROES, INIT_WITH_GAPS, INIT_WITH_CUSTOM_DATA, INIT_WITH_GAPS_OPENED = 0, 1, 2, 3
-BEST_NOWHERE, BEST_ANYWHERE, BEST_LAST_CELL, BEST_LAST_ROW, BEST_LAST_COL = 0, 1, 2, 3, 4
+BEST_NOWHERE, BEST_ANYWHERE, BEST_LAST_CELL, BEST_LAST_ROW, BEST_LAST_COL, BEST_LAST_ROW_OR_COL = 0, 1, 2, 3, 4, 5
 
 CELL = np.dtype([("h", "<i4"), ("f", "<i4")])
 
@@ -179,7 +179,7 @@ def _write_fasta(path, seq, name):
             f.write(b[i:i + 70] + b"\n")
 
 
-def run_ref(seq0, seq1, args=(), workdir=None, keep=False, timeout=3600):
+def run_ref(seq0, seq1, args=(), workdir=None, keep=False, timeout=300):
     """Run oracle/_ref/ref_driver on the pair; returns dict with best + special rows read back
     from the reference's own on-disk formats."""
     assert have_ref(), "oracle/_ref/ref_driver not built (needs /root/reference)"

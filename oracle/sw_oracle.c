@@ -296,16 +296,26 @@ int oracle_stage1(const oc_params* p, oc_result* r) {
     if (p->best_mode == OC_BEST_LAST_CELL) {
         /* AbstractBlockAligner.cpp:317-323; AlignerManager.cpp:430-434 */
         best_add(&r->best, -OC_INF, m, n, rowbuf[n - 1].h);
-    } else if (p->best_mode == OC_BEST_LAST_ROW && r->last_row) {
-        /* AlignerManager::dispatchRow (:386-393) + findBestCell (:604-616), per dispatched chunk */
+    }
+    if ((p->best_mode == OC_BEST_LAST_ROW || p->best_mode == OC_BEST_LAST_ROW_OR_COL) && r->last_row) {
+        /* AlignerManager::dispatchRow (:386-393) + findBestCell (:604-616), per dispatched chunk:
+         * first the border cell alone, then one chunk per block; j = J0 + lastRowPos + best_id */
+        best_add(&r->best, -OC_INF, m, 0, r->last_row[0].h);
         for (int bx = 0; bx < gw; bx++) {
             int j0 = bx * bw, j1 = (j0 + bw > n) ? n : j0 + bw;
-            int lo = (bx == 0) ? 0 : 1 + j0, hi = 1 + j1;   /* first dispatch = corner cell alone */
-            if (bx == 0) best_add(&r->best, -OC_INF, m, 0, r->last_row[0].h);
-            lo = 1 + j0;
-            int bid = lo, bsc = -OC_INF;
-            for (int k = lo; k < hi; k++) if (bsc < r->last_row[k].h) { bsc = r->last_row[k].h; bid = k; }
+            int bid = 1 + j0, bsc = -OC_INF;
+            for (int k = 1 + j0; k < 1 + j1; k++) if (bsc < r->last_row[k].h) { bsc = r->last_row[k].h; bid = k; }
             best_add(&r->best, -OC_INF, m, bid, bsc);
+        }
+    }
+    if ((p->best_mode == OC_BEST_LAST_COL || p->best_mode == OC_BEST_LAST_ROW_OR_COL) && r->last_col) {
+        /* AlignerManager::dispatchColumn (:340-357): i = I0 + lastColumnPos + best_id, j = J1 */
+        best_add(&r->best, -OC_INF, 0, n, r->last_col[0].h);
+        for (int by = 0; by < gh; by++) {
+            int i0 = by * bh, i1 = (i0 + bh > m) ? m : i0 + bh;
+            int bid = 1 + i0, bsc = -OC_INF;
+            for (int k = 1 + i0; k < 1 + i1; k++) if (bsc < r->last_col[k].h) { bsc = r->last_col[k].h; bid = k; }
+            best_add(&r->best, -OC_INF, bid, n, bsc);
         }
     }
 

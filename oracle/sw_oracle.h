@@ -45,6 +45,7 @@ typedef struct { int i; int j; int score; } oc_score;
 #define OC_BEST_LAST_CELL 2   /* only H[m][n] (global NW, "++")   */
 #define OC_BEST_LAST_ROW  3
 #define OC_BEST_LAST_COL  4
+#define OC_BEST_LAST_ROW_OR_COL 5
 
 /* CPUBlockProcessor::processBlock, M/libmasa/processors/CPUBlockProcessor.cpp:113-174 */
 oc_score oracle_process_block(const unsigned char* seq0, const unsigned char* seq1,

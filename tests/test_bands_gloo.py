@@ -1,0 +1,125 @@
+"""CPU, world_size 2 (gloo): the column-band driver (masa-cudalign_amd/bands.py) streams the boundary
+column between ranks while both bands are running, and the reduced best equals the single-band answer.
+The compute engine is a test double built on the oracle (the product engine needs a GPU)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class OracleStreamEngine:
+    """Same streaming surface as MI355Aligner (streamBegin/Poll/FeedColumn/ReadColumn/End), computing
+    row segments with the oracle as soon as their first-column rows have arrived."""
+
+    def __init__(self, oracle, seq0, seq1, seg=256):
+        self.o, self.s0, self.s1, self.seg = oracle, seq0, seq1, seg
+
+    def streamBegin(self, part, recurrence_type=1, track_best=True, first_row_init_type=0, first_row_start_offset=0,
+                    want_last_column=False, first_column_init_type=0, stream_first_column=False, first_column=None, **kw):
+        o = self.o
+        self.part, self.rec = part, recurrence_type
+        self.m, self.n = part.i1 - part.i0, part.j1 - part.j0
+        self.row = o.initial_cells(first_row_init_type, first_row_start_offset, self.n + 1)
+        self.custom_col = first_column_init_type == o.INIT_WITH_CUSTOM_DATA
+        self.col = np.zeros((self.m + 1, 2), dtype=np.int32)
+        if self.custom_col:
+            self.col[0] = first_column[0]
+            self.fed = 0 if stream_first_column else self.m
+        else:
+            self.col[:] = o.initial_cells(first_column_init_type, 0, self.m + 1)
+            self.fed = self.m
+        self.row[0] = self.col[0]
+        self.done = 0
+        self.last_col = np.zeros((self.m, 2), dtype=np.int32)
+        self.cands = []
+
+    def streamFeedColumn(self, row, cells):
+        assert row == self.fed
+        self.col[1 + row:1 + row + len(cells)] = cells
+        self.fed += len(cells)
+
+    def _advance(self):
+        o = self.o
+        while self.done < self.m:
+            r1 = min(self.done + self.seg, self.m)
+            if self.fed < r1:
+                return
+            r0 = self.done
+            res = o.stage1(self.s0[self.part.i0 + r0:self.part.i0 + r1], self.s1[self.part.j0:self.part.j1],
+                           recurrence=self.rec, first_row_type=o.INIT_WITH_CUSTOM_DATA, custom_first_row=self.row,
+                           first_col_type=o.INIT_WITH_CUSTOM_DATA, custom_first_col=self.col[r0:r1 + 1],
+                           want_last_row=True, want_last_col=True, block_h=64, block_w=128)
+            self.row = res["last_row"]
+            self.last_col[r0:r1] = res["last_col"][1:]
+            b = res["best"]
+            if b[0] >= 0:
+                self.cands.append((b[0] - 1 + r0 + self.part.i0, b[1] - 1 + self.part.j0, b[2]))
+            self.done = r1
+
+    def streamPoll(self):
+        self._advance()
+        return self.done, self.done >= self.m
+
+    def streamReadColumn(self, row, length):
+        assert row + length <= self.done
+        return self.last_col[row:row + length].copy()
+
+    def streamEnd(self):
+        from masa_cudalign_amd.bands import canonical_best
+        return canonical_best(self.cands), 0
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, m, n, q):
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as graft
+    pkg = graft.load_package()
+    oracle = graft.load_oracle()
+    from masa_cudalign_amd.bands import BandRunner, band_limits
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        s0, s1 = pkg.seqgen.related_pair(m, n, cfg=41)
+        lim = band_limits(n, [1] * world)
+        eng = OracleStreamEngine(oracle, s0, s1, seg=200)
+        runner = BandRunner(eng, dist=dist, rank=rank, world=world, device=None, segment_rows=300)
+        best = runner.run(m, lim[rank], lim[rank + 1])
+        gbest = runner.reduce_best(best)
+        q.put((rank, tuple(best), tuple(gbest)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_bands_over_gloo(pkg, oracle):
+    m, n, world = 1500, 1800, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, m, n, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    s0, s1 = pkg.seqgen.related_pair(m, n, cfg=41)
+    ref = oracle.stage1(s0, s1)
+    want = (ref["best"][0] - 1, ref["best"][1] - 1, ref["best"][2])   # 0-based cell, as the engine reports
+    for rank, best, gbest in res:
+        assert gbest == want, (rank, best, gbest, want)

@@ -1,0 +1,196 @@
+"""GPU (-m gpu): the HIP strip-wavefront engine, called through the C ABI, against the oracle on the
+same seeded inputs and against the fixtures generated from the reference's own CPU path.
+Integer work: every comparison is bit-exact."""
+import numpy as np
+import pytest
+
+from helpers import load_golden, make_pair, digest, parse_args, flush_interval
+
+pytestmark = pytest.mark.gpu
+G = load_golden()
+EDGE = {0: "AT_ANYWHERE", 1: "AT_SEQUENCE_1", 2: "AT_SEQUENCE_2", 3: "AT_SEQUENCE_1_OR_2", 4: "AT_SEQUENCE_1_AND_2"}
+
+
+def run_stage1(pkg, al, s0, s1, start=0, end=0, interval=0, keep_last_row=False, keep_last_col=False):
+    al.setSequences(s0, s1)
+    part = pkg.Partition(0, 0, len(s0), len(s1))
+    mg = pkg.Stage1Manager(part, alignment_start=getattr(pkg, EDGE[start]), alignment_end=getattr(pkg, EDGE[end]),
+                           special_row_interval=interval, keep_last_row=keep_last_row, keep_last_column=keep_last_col)
+    al.alignPartition(part, mg)
+    al.unsetSequences()
+    return mg
+
+
+@pytest.mark.parametrize("case", G["cases"], ids=[c["name"] for c in G["cases"]])
+def test_golden_fixture(case, pkg, aligner):
+    """best score + canonical position (and special rows) against the reference-generated fixture."""
+    s0, s1 = make_pair(pkg, case["seq"])
+    p = parse_args(case["args"])
+    sr = "special_rows" in case and not case["name"].startswith("full_pipeline")
+    interval = flush_interval(len(s0), len(s1), p["disk"]) if sr else 0
+    mg = run_stage1(pkg, aligner, s0, s1, p["start"], p["end"], interval=interval, keep_last_row=sr)
+    assert list(mg.getBestScore()) == case["best"]
+    if sr:
+        got = sorted(mg.special_rows)
+        want = sorted(int(k) for k in case["special_rows"])
+        assert got == want
+        for i in got:
+            assert digest(mg.specialRow(i)) == case["special_rows"][str(i)], "special row %d" % i
+
+
+@pytest.mark.parametrize("R", [4, 8, 16])
+@pytest.mark.parametrize("m,n", [(1, 1), (1, 300), (300, 1), (63, 64), (64, 63), (255, 129), (256, 128), (257, 127),
+                                 (513, 65), (1025, 1023), (2048, 100), (5000, 4321)])
+def test_all_borders_vs_oracle_sw(pkg, oracle, R, m, n):
+    """ragged sizes (not multiples of 4/64/512, n < 64, m < strip): best, last row and last column."""
+    s0, s1 = pkg.seqgen.related_pair(m, n, cfg=m * 7 + n)
+    al = pkg.MI355Aligner(device=0, rows_per_lane=R)
+    try:
+        al.setSequences(s0, s1)
+        part = pkg.Partition(0, 0, m, n)
+        mg = pkg.Stage1Manager(part, keep_last_row=True, keep_last_column=True)
+        al.alignPartition(part, mg)
+        ref = oracle.stage1(s0, s1, block_h=64 * R, block_w=97, want_last_row=True, want_last_col=True)
+        assert tuple(mg.getBestScore()) == tuple(ref["best"])
+        assert np.array_equal(mg.lastRow(), ref["last_row"])
+        assert np.array_equal(mg.lastColumn(), ref["last_col"])
+    finally:
+        al.close()
+
+
+@pytest.mark.parametrize("start,end", [(4, 4), (1, 3), (2, 3), (3, 3), (1, 1), (2, 2)])
+def test_nw_and_semiglobal_edges(pkg, oracle, aligner, start, end):
+    from helpers import oracle_kwargs
+    m, n = 3001, 2777
+    s0, s1 = pkg.seqgen.related_pair(m, n, cfg=50 + start * 5 + end)
+    mg = run_stage1(pkg, aligner, s0, s1, start, end, keep_last_row=True, keep_last_col=True)
+    st = aligner.getStatistics()
+    kw = oracle_kwargs(oracle, dict(start=start, end=end, pruning=False, disk=-1, block=(st["strip_rows"], 1 << 20)), m, n)
+    kw.update(want_last_row=True, want_last_col=True)
+    ref = oracle.stage1(s0, s1, **kw)
+    assert np.array_equal(mg.lastRow(), ref["last_row"])
+    assert np.array_equal(mg.lastColumn(), ref["last_col"])
+    assert tuple(mg.getBestScore()) == tuple(ref["best"])
+
+
+def test_generic_compare_kernel_and_foreign_bytes(pkg, oracle):
+    """more than 7 shared byte values force the raw-compare kernels; N matches N, bytes present in one
+    sequence only never match (X/CUDAligner.cu:276-289 raw byte inequality)."""
+    rng = np.random.default_rng(5)
+    alpha = np.frombuffer(b"ACGTNRYKMSWBDHV", dtype=np.uint8)
+    s0 = alpha[rng.integers(0, len(alpha), 3000)]
+    s1 = s0.copy()
+    s1[rng.integers(0, 3000, 300)] = alpha[rng.integers(0, len(alpha), 300)]
+    s1 = np.concatenate([s1[:1500], alpha[rng.integers(0, 4, 77)], s1[1500:]])
+    for flags in (0, 1):
+        al = pkg.MI355Aligner(device=0, flags=flags)
+        try:
+            al.setSequences(s0, s1)
+            part = pkg.Partition(0, 0, len(s0), len(s1))
+            mg = pkg.Stage1Manager(part, keep_last_row=True)
+            al.alignPartition(part, mg)
+            assert al.getStatistics()["profile_kernel"] == 0
+            ref = oracle.stage1(s0, s1, want_last_row=True)
+            assert tuple(mg.getBestScore()) == tuple(ref["best"])
+            assert np.array_equal(mg.lastRow(), ref["last_row"])
+        finally:
+            al.close()
+    # ACGT+N pair with the profile kernels forced off must agree with the profile kernels
+    s0, s1 = make_pair(pkg, dict(kind="with_n", m=3000, n=3100, cfg=9))
+    res = []
+    for flags in (0, 1):
+        al = pkg.MI355Aligner(device=0, flags=flags)
+        al.setSequences(s0, s1)
+        part = pkg.Partition(0, 0, len(s0), len(s1))
+        mg = pkg.Stage1Manager(part, keep_last_column=True)
+        al.alignPartition(part, mg)
+        res.append((al.getStatistics()["profile_kernel"], tuple(mg.getBestScore()), mg.lastColumn()))
+        al.close()
+    assert res[0][0] == 1 and res[1][0] == 0
+    assert res[0][1] == res[1][1] and np.array_equal(res[0][2], res[1][2])
+
+
+def test_tie_break_canonical_position(pkg, oracle, aligner):
+    """unrelated pairs have many cells tied at the best score: (min i, then min j) must win (M5)."""
+    for cfg in range(3):
+        s0, s1 = pkg.seqgen.unrelated_pair(9000, 8000, cfg=70 + cfg)
+        mg = run_stage1(pkg, aligner, s0, s1)
+        assert tuple(mg.getBestScore()) == tuple(oracle.stage1(s0, s1)["best"])
+
+
+def test_process_block_seam(pkg, oracle, aligner):
+    """AbstractBlockProcessor::processBlock (S3): random borders incl. -INF entries, SW and NW."""
+    rng = np.random.default_rng(11)
+    s0, s1 = pkg.seqgen.related_pair(3000, 3000, cfg=81)
+    aligner.setSequences(s0, s1)
+    try:
+        for rec in (pkg.SMITH_WATERMAN, pkg.NEEDLEMAN_WUNSCH):
+            for (i0, j0, i1, j1) in [(0, 0, 700, 900), (100, 250, 1124, 314), (1000, 1000, 1001, 2500), (5, 7, 1500, 8)]:
+                m, n = i1 - i0, j1 - j0
+                row = np.stack([rng.integers(0, 50, n), rng.integers(-60, 40, n)], axis=1).astype(np.int32)
+                col = np.stack([rng.integers(0, 50, m + 1), rng.integers(-60, 40, m + 1)], axis=1).astype(np.int32)
+                row[rng.integers(0, n, max(1, n // 10)), 1] = -pkg.INF
+                col[1 + rng.integers(0, m, max(1, m // 10)), 1] = -pkg.INF
+                r1, c1 = row.copy(), col.copy()
+                b1 = oracle.process_block(s0, s1, r1, c1, i0, j0, i1, j1, rec)
+                r2, c2 = row.copy(), col.copy()
+                b2 = aligner.processBlock(r2, c2, i0, j0, i1, j1, rec)
+                assert np.array_equal(r1, r2) and np.array_equal(c1, c2)
+                assert tuple(b1) == tuple(b2)
+    finally:
+        aligner.unsetSequences()
+
+
+def test_streamed_column_bands_on_one_gpu(pkg, oracle):
+    """the 8-GPU chain emulated on one GPU: bands run one after the other, each fed with the previous
+    band's last column through the streaming ABI; boundary columns and bests match the reference chain."""
+    ch = G["chain"]
+    s0, s1 = make_pair(pkg, ch["seq"])
+    n, parts = len(s1), ch["parts"]
+    from masa_cudalign_amd.bands import band_limits, canonical_best
+    lim = band_limits(n, [1] * parts)
+    al = pkg.MI355Aligner(device=0)
+    try:
+        al.setSequences(s0, s1)
+        col, cands = None, []
+        for k in range(parts):
+            part = pkg.Partition(0, lim[k], len(s0), lim[k + 1])
+            kw = dict(want_last_column=True)
+            if col is not None:
+                kw.update(first_column_init_type=pkg.INIT_WITH_CUSTOM_DATA, stream_first_column=True, first_column=col[:1])
+            al.streamBegin(part, **kw)
+            fed = 0
+            while True:
+                if col is not None and fed < len(s0):
+                    ln = min(777, len(s0) - fed)
+                    al.streamFeedColumn(fed, col[1 + fed:1 + fed + ln])
+                    fed += ln
+                rows, fin = al.streamPoll()
+                if fin:
+                    break
+            newcol = np.concatenate([np.array([[0, -pkg.INF]], dtype=np.int32), al.streamReadColumn(0, len(s0))])
+            best, _ = al.streamEnd()
+            if k < parts - 1:
+                assert digest(newcol) == ch["boundary_columns"]["STEP-%d.tmp" % (k + 1)]
+            col = newcol
+            cands.append(best)
+            run = canonical_best(cands)
+            assert [run[0] + 1, run[1] + 1, run[2]] == ch["band_bests"][k]
+    finally:
+        al.close()
+
+
+def test_large_roundtrip_properties(pkg, aligner):
+    """full-size style check without an oracle run: a pair with a planted exact repeat must score at
+    least the repeat length, symmetric roles give the same score, and two runs are bit-identical."""
+    m = n = 300000
+    s0, s1 = pkg.seqgen.unrelated_pair(m, n, cfg=90)
+    s1 = s1.copy()
+    s1[120000:120400] = s0[200000:200400]
+    a = tuple(run_stage1(pkg, aligner, s0, s1).getBestScore())
+    b = tuple(run_stage1(pkg, aligner, s0, s1).getBestScore())
+    c = tuple(run_stage1(pkg, aligner, s1, s0).getBestScore())
+    assert a == b
+    assert a[2] >= 400 and a[2] == c[2]
+    assert (a[0], a[1]) == (c[1], c[0])
+    assert abs(a[0] - 200400) <= 40 and abs(a[1] - 120400) <= 40

@@ -1,0 +1,67 @@
+"""CPU: host-side mirror of the caller (manager.py), band splitting, generator determinism."""
+import hashlib
+
+import numpy as np
+
+
+def test_initial_cells_reader_matches_oracle(pkg, oracle):
+    for (go, ge, typ) in [(0, 0, oracle.INIT_WITH_ZEROES), (3, 2, oracle.INIT_WITH_GAPS), (0, 2, oracle.INIT_WITH_GAPS_OPENED)]:
+        for off in (0, 1, 777):
+            rd = pkg.InitialCellsReader(go, ge, off)
+            assert rd.getType() == typ
+            a = np.empty((50, 2), dtype=np.int32)
+            rd.read(a, 1)
+            rd.read(a[1:], 49)
+            assert np.array_equal(a, oracle.initial_cells(typ, off, 50))
+
+
+def test_best_score_list_order(pkg):
+    b = pkg.BestScoreList(0)
+    for t in [(5, 9, 10), (4, 20, 10), (4, 3, 10), (1, 1, 9), (9, 9, -1)]:
+        b.add(*t)
+    assert b.getBestScore() == (4, 3, 10)
+    assert pkg.BestScoreList(0).getBestScore() == (-1, -1, -pkg.INF)
+
+
+def test_band_limits_follow_reference_split(pkg):
+    # libmasa.cpp:511-512 : trim_j0 = len*P[s-1]/sum + 1 (1-based), trim_j1 = len*P[s]/sum
+    from masa_cudalign_amd.bands import band_limits
+    n, w = 1000003, [100, 100, 250, 50]
+    lim = band_limits(n, w)
+    acc = np.cumsum([0] + w)
+    for s in range(1, len(w) + 1):
+        assert lim[s - 1] + 1 == n * int(acc[s - 1]) // int(acc[-1]) + 1
+        assert lim[s] == n * int(acc[s]) // int(acc[-1])
+    assert lim[0] == 0 and lim[-1] == n
+
+
+def test_generator_is_deterministic(pkg):
+    a = pkg.seqgen.random_dna(0xC0FFEE00, 1000)
+    assert hashlib.sha256(a.tobytes()).hexdigest() == hashlib.sha256(pkg.seqgen.random_dna(0xC0FFEE00, 1000, chunk=64).tobytes()).hexdigest()
+    assert set(np.unique(a)) <= set(b"ACGT")
+    s0, s1 = pkg.seqgen.related_pair(5000, 4000, cfg=1)
+    t0, t1 = pkg.seqgen.related_pair(5000, 4000, cfg=1)
+    assert np.array_equal(s0, t0) and np.array_equal(s1, t1) and len(s1) == 4000
+
+
+def test_stage1_manager_on_oracle_rows(pkg, oracle):
+    """drive the Python manager mirror with rows/columns produced by the oracle and compare its
+    bookkeeping (semi-global best on last row/column) with the oracle's own."""
+    s0, s1 = pkg.seqgen.related_pair(700, 900, cfg=5)
+    r = oracle.stage1(s0, s1, recurrence=oracle.NEEDLEMAN_WUNSCH, first_col_type=oracle.INIT_WITH_GAPS,
+                      block_h=128, block_w=200, want_last_row=True, want_last_col=True,
+                      best_mode=oracle.BEST_LAST_ROW_OR_COL)
+    part = pkg.Partition(0, 0, 700, 900)
+    mg = pkg.Stage1Manager(part, alignment_start=pkg.AT_SEQUENCE_1, alignment_end=pkg.AT_SEQUENCE_1_OR_2)
+    assert mg.getRecurrenceType() == pkg.NEEDLEMAN_WUNSCH
+    assert mg.getFirstColumnInitType() == pkg.INIT_WITH_GAPS and mg.getFirstRowInitType() == pkg.INIT_WITH_ZEROES
+    lr, lc = r["last_row"], r["last_col"]
+    mg.dispatchColumn(900, lc[:1], 1)
+    for i in range(0, 700, 128):
+        ch = lc[1 + i:1 + min(i + 128, 700)]
+        mg.dispatchColumn(900, ch, len(ch))
+    mg.dispatchRow(700, lr[:1], 1)
+    for j in range(0, 900, 200):
+        ch = lr[1 + j:1 + min(j + 200, 900)]
+        mg.dispatchRow(700, ch, len(ch))
+    assert tuple(mg.getBestScore()) == tuple(r["best"])

@@ -1,0 +1,65 @@
+"""CPU: the C restatement (oracle/sw_oracle.c) against the fixtures generated from the reference's own
+MASA-Core CPU path (tests/golden/stage1_cases.json, made by oracle/make_golden.py)."""
+import hashlib
+
+import numpy as np
+import pytest
+
+from helpers import load_golden, make_pair, digest, parse_args, oracle_kwargs
+
+G = load_golden()
+
+
+@pytest.mark.parametrize("case", G["cases"], ids=[c["name"] for c in G["cases"]])
+def test_oracle_matches_reference_fixture(case, pkg, oracle):
+    s0, s1 = make_pair(pkg, case["seq"])
+    assert hashlib.sha256(s0.tobytes()).hexdigest() == case["seq0_sha256"]
+    assert hashlib.sha256(s1.tobytes()).hexdigest() == case["seq1_sha256"]
+    p = parse_args(case["args"])
+    kw = oracle_kwargs(oracle, p, len(s0), len(s1))
+    r = oracle.stage1(s0, s1, **kw)
+    assert list(r["best"]) == case["best"]
+    if "special_rows" in case:
+        ids = r["special_row_ids"]
+        for key, dg in case["special_rows"].items():
+            i = int(key)
+            row = r["special_rows"][ids.index(i)] if i in ids else r["last_row"]
+            assert digest(row) == dg, "special row %d" % i
+
+
+def test_oracle_geometry_invariance(pkg, oracle):
+    """best score/position and every border are independent of the block geometry."""
+    s0, s1 = pkg.seqgen.related_pair(2500, 3100, cfg=21)
+    base = oracle.stage1(s0, s1, block_h=2500, block_w=3100, want_last_row=True, want_last_col=True)
+    for bh, bw in [(1, 3100), (7, 13), (64, 64), (512, 100), (1000, 1)]:
+        r = oracle.stage1(s0, s1, block_h=bh, block_w=bw, want_last_row=True, want_last_col=True)
+        assert r["best"] == base["best"]
+        assert np.array_equal(r["last_row"], base["last_row"])
+        assert np.array_equal(r["last_col"], base["last_col"])
+    mt = oracle.stage1(s0, s1, block_h=128, block_w=128, threads=4)
+    assert mt["best"] == base["best"]
+
+
+def test_oracle_chain_matches_reference(pkg, oracle):
+    """column bands chained through the boundary column reproduce the reference's --split run."""
+    ch = G["chain"]
+    s0, s1 = make_pair(pkg, ch["seq"])
+    n, parts = len(s1), ch["parts"]
+    lim = [n * k // parts for k in range(parts + 1)]
+    col = None
+    cands = []
+    for k in range(parts):
+        j0, j1 = lim[k], lim[k + 1]
+        kw = dict(want_last_col=True, row_start_offset=j0)
+        if col is not None:
+            kw.update(first_col_type=oracle.INIT_WITH_CUSTOM_DATA, custom_first_col=col)
+        r = oracle.stage1(s0, s1[j0:j1], **kw)
+        col = r["last_col"]
+        if k < parts - 1:
+            assert digest(col) == ch["boundary_columns"]["STEP-%d.tmp" % (k + 1)]
+        b = r["best"]
+        cands.append((b[0], b[1] + j0, b[2]))
+        # the reference relays the running best down the chain (sw_stage1.cpp:421-426, 459-464)
+        run = max(cands, key=lambda t: (t[2], -t[0], -t[1]))
+        assert list(run) == ch["band_bests"][k]
+    assert list(run) == ch["single_best"]
