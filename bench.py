@@ -1,0 +1,198 @@
+#!/usr/bin/env python3
+"""Stage-1 GCUPS bench (BASELINE.json metric) for the MI355X strip-wavefront engine.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one complete Stage-1 pass (score + canonical position) over the synthetic pair with both
+sequences already resident in HBM.
+  N = 1 : BASELINE config C2, 3,000,000 x 3,000,000 unrelated random ACGT, local SW, score-only.
+  N > 1 : weak scaling, per-GPU work fixed at 9e12 cells: (3,000,000*N) x 3,000,000, seq1 cut into N
+          column bands, boundary column streamed rank g -> g+1 over RCCL point-to-point (bands.py).
+Rank 0 prints ONE JSON line.  GCUPS convention of the reference: cells = m*n (sw_stage1.cpp:440-448).
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as graft  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0                 # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+# int32 VALU issue measured on this chip (tools/micro_valu.hip): 1 wave64 op / 4 cycles / SIMD
+VALU_PEAK_LANE_OPS = 256 * 4 * 16 * 2.4e9
+
+
+def cpu_baseline(pkg, seconds_budget=20.0):
+    """MASA-Core's own CPU aligner path (oracle/_ref/ref_driver = reference sources compiled as-is) timed
+    on this host, 1 thread, on a bounded sample of the same workload; falls back to the C restatement."""
+    oracle = graft.load_oracle()
+    side = 60000
+    s0, s1 = pkg.seqgen.unrelated_pair(side, side, cfg=1)
+    if oracle.have_ref():
+        tmp = tempfile.mkdtemp(prefix="bench_ref_")
+        try:
+            t0 = time.time()
+            ref = oracle.run_ref(s0, s1, ["--stage-1", "--no-flush"], workdir=tmp, timeout=600)
+            dt = time.time() - t0
+            # use the reference's own ALIGN timer when present (excludes FASTA parsing)
+            ms = None
+            try:
+                for ln in open(os.path.join(tmp, "work", "statistics_01.00")):
+                    if ln.strip().startswith("ALIGN:"):
+                        ms = float(ln.split()[1])
+            except OSError:
+                pass
+            if ms:
+                dt = ms / 1000.0
+            return {"value": side * side / dt / 1e9, "unit": "GCUPS", "cores": 1, "kind": "reference",
+                    "sample": "%dx%d unrelated SW stage-1, MASA-Core CPUBlockProcessor path (oracle/_ref), best=%s"
+                              % (side, side, list(ref["best"]))}
+        finally:
+            import shutil
+            shutil.rmtree(tmp, ignore_errors=True)
+    t0 = time.time()
+    r = oracle.stage1(s0, s1)
+    dt = time.time() - t0
+    return {"value": side * side / dt / 1e9, "unit": "GCUPS", "cores": 1, "kind": "port",
+            "sample": "%dx%d unrelated SW stage-1, oracle/sw_oracle.c, best=%s" % (side, side, list(r["best"]))}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--size", type=int, default=3000000, help="n (and m per GPU) of the synthetic pair")
+    ap.add_argument("--rows-per-lane", type=int, default=int(os.environ.get("MI355SW_R", "0")))
+    ap.add_argument("--waves", type=int, default=int(os.environ.get("MI355SW_WAVES", "0")))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N>1 with torch.distributed.run (one rank per GPU)")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X; the engine has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    comm = os.environ.get("MI355SW_BENCH_COMM", "nccl")
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        p2p_group = dist.new_group(backend="gloo") if comm == "gloo" else None
+
+    pkg = graft.load_package()
+    from masa_cudalign_amd.bands import BandRunner, band_limits
+
+    n = args.size
+    m = args.size * world
+    s0, s1 = pkg.seqgen.unrelated_pair(m, n, cfg=2)
+    al = pkg.MI355Aligner(device=local_rank, rows_per_lane=args.rows_per_lane, waves=args.waves)
+    al.setSequences(s0, s1)            # H2D once, outside the timed region
+    lim = band_limits(n, [1] * world)
+    j0, j1 = lim[rank], lim[rank + 1]
+
+    class _Dist:                       # boundary-column transport: RCCL p2p (device tensors) or gloo (host)
+        def __init__(self):
+            self.group = p2p_group if world > 1 else None
+
+        def send(self, t, dst):
+            dist.send(t, dst=dst, group=self.group)
+
+        def recv(self, t, src):
+            dist.recv(t, src=src, group=self.group)
+
+        def all_gather(self, out, t):
+            dist.all_gather(out, t)
+
+    runner = BandRunner(al, dist=_Dist() if world > 1 else None, rank=rank, world=world,
+                        device=(device if (world > 1 and comm == "nccl") else None), segment_rows=1 << 15)
+    if world > 1 and comm != "nccl":
+        runner.reduce_best = lambda b, _r=runner: _reduce_cpu(dist, b, world, device)
+
+    def one_step():
+        best = runner.run(m, j0, j1)
+        if world > 1:
+            best = runner.reduce_best(best)
+        return best, al.getStatistics()
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    best = None
+    for _ in range(args.warmup):
+        best, _st = one_step()
+    fence()
+    t0 = time.time()
+    kernel_ms = []
+    for _ in range(args.steps):
+        best, st = one_step()
+        kernel_ms.append(st["kernel_ms"])
+    fence()
+    dt = time.time() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        cells = float(m) * float(n)
+        gcups = cells * args.steps / dt / 1e9
+        k_ms = sum(kernel_ms) / len(kernel_ms)
+        alg_bytes = st["algorithmic_bytes"]
+        achieved = alg_bytes / (k_ms * 1e-3) / 1e9
+        band_cells = float(m) * float(j1 - j0)
+        out = {
+            "metric": "GCUPS (DP cells/sec) Stage-1", "value": gcups, "unit": "GCUPS",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+            "config": {"workload": ("C2: %dx%d unrelated random ACGT, local SW, score-only" % (m, n)) if world == 1 else
+                       ("weak scaling of C2: (%d*%d)x%d, %d column bands of %d columns, boundary column over RCCL p2p"
+                        % (args.size, world, n, world, n // world)),
+                       "m": m, "n": n, "bands": world, "strip_rows": st["strip_rows"], "waves_per_gpu": st["waves"],
+                       "kernel": "profile" if st["profile_kernel"] else "generic", "comm": comm if world > 1 else "none"},
+            "best": {"i": best[0] + 1, "j": best[1] + 1, "score": best[2]},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "sw_strip_kernel", "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_bytes,
+                         "note": "scan kernel: 17 B per column per %d-row strip; the binding unit is int32 VALU issue" % st["strip_rows"]},
+            "valu_roofline": {"ops_per_cell": 10.8, "achieved_lane_ops": band_cells * 10.8 / (k_ms * 1e-3),
+                              "peak_lane_ops": VALU_PEAK_LANE_OPS,
+                              "frac": band_cells * 10.8 / (k_ms * 1e-3) / VALU_PEAK_LANE_OPS},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(pkg)
+        print(json.dumps(out), flush=True)
+    al.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def _reduce_cpu(dist, best, world, device):
+    import torch
+    from masa_cudalign_amd.bands import canonical_best
+    t = torch.tensor(list(best), dtype=torch.int64, device=device)
+    out = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(out, t)
+    return canonical_best([tuple(int(x) for x in o.tolist()) for o in out])
+
+
+if __name__ == "__main__":
+    main()
