@@ -88,11 +88,14 @@ def main():
         raise SystemExit("bench.py needs an MI355X; the engine has no CPU fallback")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    comm = os.environ.get("MI355SW_BENCH_COMM", "nccl")
+    # boundary-column transport between bands: "host" = pinned zero-copy columns + gloo between the
+    # rank processes (no GPU queue involved while the persistent kernels run; default), "nccl" = RCCL
+    # send/recv of device tensors over xGMI (needs free CU resources next to the strip kernel)
+    comm = os.environ.get("MI355SW_BENCH_COMM", "host")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
-        p2p_group = dist.new_group(backend="gloo") if comm == "gloo" else None
+        p2p_group = dist.new_group(backend="gloo") if comm != "nccl" else None
 
     pkg = graft.load_package()
     from masa_cudalign_amd.bands import BandRunner, band_limits
@@ -100,7 +103,10 @@ def main():
     n = args.size
     m = args.size * world
     s0, s1 = pkg.seqgen.unrelated_pair(m, n, cfg=2)
-    al = pkg.MI355Aligner(device=local_rank, rows_per_lane=args.rows_per_lane, waves=args.waves)
+    waves = args.waves
+    if waves == 0 and world > 1 and comm == "nccl":
+        waves = 256 * 12            # leave VGPR room on every SIMD for RCCL's send/recv kernels
+    al = pkg.MI355Aligner(device=local_rank, rows_per_lane=args.rows_per_lane, waves=waves)
     al.setSequences(s0, s1)            # H2D once, outside the timed region
     lim = band_limits(n, [1] * world)
     j0, j1 = lim[rank], lim[rank + 1]

@@ -34,6 +34,13 @@ struct DevBuf {
     size_t cap = 0;
 };
 
+// host-pinned, device-mapped buffer: the running strip kernel reads/writes it directly over PCIe, so
+// streaming the border columns needs NO copy queued behind (or beside) the persistent kernel.
+struct PinBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+};
+
 double now_ms() {
     using namespace std::chrono;
     return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
@@ -58,7 +65,9 @@ struct mi355sw_handle {
     int n_match_codes = 0, pad_code = 0;
 
     // work buffers
-    DevBuf d_bus, d_first_col, d_last_col, d_special, d_last_row, d_progress, d_strip_best, d_ctrl;
+    DevBuf d_bus, d_first_col, d_special, d_last_row, d_progress, d_strip_best, d_ctrl;
+    PinBuf p_first_col, p_last_col;  // streamed first column / last column (zero-copy)
+    bool first_col_pinned = false;
     int* h_pinned = nullptr;        // [0] strips_done (kernel->host) [16] first_col_ready (host->kernel)
     std::vector<int4> strip_best_host;
 
@@ -96,6 +105,16 @@ static int ensure(mi355sw_handle* h, DevBuf& b, size_t bytes) {
     size_t want = std::max<size_t>(bytes, 256);
     hipError_t e = hipMalloc(&b.p, want);
     if (e != hipSuccess) FAIL(h, MI355SW_ENOMEM, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+    b.cap = want;
+    return MI355SW_OK;
+}
+
+static int ensure_pinned(mi355sw_handle* h, PinBuf& b, size_t bytes) {
+    if (bytes <= b.cap && b.p) return MI355SW_OK;
+    if (b.p) { (void) hipHostFree(b.p); b.p = nullptr; b.cap = 0; }
+    size_t want = std::max<size_t>(bytes, 4096);
+    hipError_t e = hipHostMalloc(&b.p, want, hipHostMallocMapped);
+    if (e != hipSuccess) FAIL(h, MI355SW_ENOMEM, "hipHostMalloc(%zu) failed: %s", want, hipGetErrorString(e));
     b.cap = want;
     return MI355SW_OK;
 }
@@ -148,7 +167,12 @@ int mi355sw_create(const mi355sw_config* config, mi355sw_handle** out) {
         return MI355SW_ENOGPU;
     }
     h->compute_units = prop.multiProcessorCount;
-    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess ||
+    // The persistent strip kernel owns its hardware queue for seconds.  HIP multiplexes streams onto a
+    // few HSA queues per priority level; a copy queued on a stream that shares the kernel's queue would
+    // sit behind it forever.  The kernel stream therefore lives alone in the high-priority pool.
+    int prio_lo = 0, prio_hi = 0;
+    (void) hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+    if (hipStreamCreateWithPriority(&h->stream, hipStreamNonBlocking, prio_hi) != hipSuccess ||
         hipStreamCreateWithFlags(&h->copy, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess ||
         hipHostMalloc((void**) &h->h_pinned, 256, hipHostMallocMapped) != hipSuccess) {
@@ -165,7 +189,9 @@ void mi355sw_destroy(mi355sw_handle* h) {
     (void) hipSetDevice(h->device);
     if (h->active) { mi355sw_stream_abort(h); mi355sw_stream_end(h, nullptr, nullptr); }
     release(h->d_seq0); release(h->d_seq1); release(h->d_bus); release(h->d_first_col);
-    release(h->d_last_col); release(h->d_special); release(h->d_last_row); release(h->d_progress);
+    if (h->p_first_col.p) (void) hipHostFree(h->p_first_col.p);
+    if (h->p_last_col.p) (void) hipHostFree(h->p_last_col.p);
+    release(h->d_special); release(h->d_last_row); release(h->d_progress);
     release(h->d_strip_best); release(h->d_ctrl);
     if (h->h_pinned) (void) hipHostFree(h->h_pinned);
     if (h->ev0) (void) hipEventDestroy(h->ev0);
@@ -300,8 +326,11 @@ int mi355sw_stream_begin(mi355sw_handle* h, const mi355sw_partition* part, const
     if ((rc = ensure(h, h->d_strip_best, sizeof(int4) * (size_t) h->strips))) return rc;
     if ((rc = ensure(h, h->d_ctrl, 256))) return rc;
     const bool need_first_col = (p->first_column_init_type != MI355SW_INIT_WITH_ZEROES);
-    if (need_first_col && (rc = ensure(h, h->d_first_col, sizeof(int2) * ((size_t) m + 1)))) return rc;
-    if (p->want_last_column && (rc = ensure(h, h->d_last_col, sizeof(int2) * ((size_t) m + 1)))) return rc;
+    h->first_col_pinned = need_first_col && p->first_column_init_type == MI355SW_INIT_WITH_CUSTOM_DATA &&
+                          p->stream_first_column;
+    if (need_first_col && !h->first_col_pinned && (rc = ensure(h, h->d_first_col, sizeof(int2) * ((size_t) m + 1)))) return rc;
+    if (h->first_col_pinned && (rc = ensure_pinned(h, h->p_first_col, sizeof(int2) * ((size_t) m + 1)))) return rc;
+    if (p->want_last_column && (rc = ensure_pinned(h, h->p_last_col, sizeof(int2) * ((size_t) m + 1)))) return rc;
     if (p->want_last_row && (rc = ensure(h, h->d_last_row, sizeof(int2) * ((size_t) n + 64)))) return rc;
     if (h->n_special > 0) {
         const size_t bytes = sizeof(int2) * (size_t) h->special_pitch * h->n_special;
@@ -334,11 +363,11 @@ int mi355sw_stream_begin(mi355sw_handle* h, const mi355sw_partition* part, const
                 HIPCHK(h, hipStreamSynchronize(h->stream));
                 h->h_pinned[16] = m;
                 h->fed_rows = m;
-            } else if (p->first_column) {
-                // only the corner is known up front
-                HIPCHK(h, hipMemcpyAsync(h->d_first_col.p, p->first_column, sizeof(int2), hipMemcpyHostToDevice,
-                                         h->stream));
-                HIPCHK(h, hipStreamSynchronize(h->stream));
+            } else {
+                // only the corner is known up front; rows arrive through mi355sw_stream_feed_column()
+                mi355sw_cell corner = {0, -MI355SW_INF};
+                if (p->first_column) corner = p->first_column[0];
+                memcpy(h->p_first_col.p, &corner, sizeof(corner));
             }
         } else {
             // InitialCellsReader (InitialCellsReader.cpp:84-108) generated on the host once
@@ -373,8 +402,8 @@ int mi355sw_stream_begin(mi355sw_handle* h, const mi355sw_partition* part, const
     a.strip_row0 = 0;
     a.strip_index0 = 0;
     a.bus = (int2*) h->d_bus.p;
-    a.first_col = need_first_col ? (const int2*) h->d_first_col.p : nullptr;
-    a.last_col = p->want_last_column ? (int2*) h->d_last_col.p : nullptr;
+    a.first_col = need_first_col ? (const int2*) (h->first_col_pinned ? h->p_first_col.p : h->d_first_col.p) : nullptr;
+    a.last_col = p->want_last_column ? (int2*) h->p_last_col.p : nullptr;
     a.special_rows = h->n_special > 0 ? (int2*) h->d_special.p : nullptr;
     a.special_pitch = h->special_pitch;
     a.special_interval_strips = h->n_special > 0 ? h->special_interval_strips : 0;
@@ -411,11 +440,11 @@ int mi355sw_stream_begin(mi355sw_handle* h, const mi355sw_partition* part, const
 
 int mi355sw_stream_feed_column(mi355sw_handle* h, int32_t row, const mi355sw_cell* cells, int32_t len) {
     if (!h || !h->active) return MI355SW_ESTATE;
+    if (!h->first_col_pinned) FAIL(h, MI355SW_ESTATE, "feed_column without a streamed first column");
     if (row != h->fed_rows || len < 0 || row + len > h->m) FAIL(h, MI355SW_EINVAL, "feed_column out of order");
     if (len == 0) return MI355SW_OK;
-    HIPCHK(h, hipMemcpyAsync((int2*) h->d_first_col.p + 1 + row, cells, sizeof(int2) * (size_t) len,
-                             hipMemcpyHostToDevice, h->copy));
-    HIPCHK(h, hipStreamSynchronize(h->copy));
+    // zero-copy: the kernel reads these cells straight from pinned host memory (system-scope loads)
+    memcpy((mi355sw_cell*) h->p_first_col.p + 1 + row, cells, sizeof(mi355sw_cell) * (size_t) len);
     h->fed_rows += len;
     __atomic_store_n(&h->h_pinned[16], h->fed_rows, __ATOMIC_RELEASE);
     return MI355SW_OK;
@@ -425,8 +454,10 @@ int mi355sw_stream_feed_column_device(mi355sw_handle* h, int32_t row, const void
     if (!h || !h->active) return MI355SW_ESTATE;
     if (row != h->fed_rows || len < 0 || row + len > h->m) FAIL(h, MI355SW_EINVAL, "feed_column_device out of order");
     if (len == 0) return MI355SW_OK;
-    HIPCHK(h, hipMemcpyAsync((int2*) h->d_first_col.p + 1 + row, dev_cells, sizeof(int2) * (size_t) len,
-                             hipMemcpyDeviceToDevice, h->copy));
+    if (!h->first_col_pinned) FAIL(h, MI355SW_ESTATE, "feed_column_device without a streamed first column");
+    // D2H into the pinned column on the copy stream (a queue of its own: see mi355sw_create)
+    HIPCHK(h, hipMemcpyAsync((int2*) h->p_first_col.p + 1 + row, dev_cells, sizeof(int2) * (size_t) len,
+                             hipMemcpyDeviceToHost, h->copy));
     HIPCHK(h, hipStreamSynchronize(h->copy));
     h->fed_rows += len;
     __atomic_store_n(&h->h_pinned[16], h->fed_rows, __ATOMIC_RELEASE);
@@ -436,8 +467,8 @@ int mi355sw_stream_feed_column_device(mi355sw_handle* h, int32_t row, const void
 int mi355sw_stream_read_column_device(mi355sw_handle* h, int32_t row, void* dev_cells, int32_t len) {
     if (!h || !h->active || !h->sp.want_last_column) return MI355SW_ESTATE;
     if (row < 0 || len < 0 || row + len > h->m) FAIL(h, MI355SW_EINVAL, "read_column_device range");
-    HIPCHK(h, hipMemcpyAsync(dev_cells, (int2*) h->d_last_col.p + 1 + row, sizeof(int2) * (size_t) len,
-                             hipMemcpyDeviceToDevice, h->copy));
+    HIPCHK(h, hipMemcpyAsync(dev_cells, (int2*) h->p_last_col.p + 1 + row, sizeof(int2) * (size_t) len,
+                             hipMemcpyHostToDevice, h->copy));
     HIPCHK(h, hipStreamSynchronize(h->copy));
     return MI355SW_OK;
 }
@@ -450,8 +481,8 @@ int mi355sw_stream_publish_first_column(mi355sw_handle* h, int32_t rows) {
     return MI355SW_OK;
 }
 
-void* mi355sw_stream_device_first_column(mi355sw_handle* h) { return h ? h->d_first_col.p : nullptr; }
-void* mi355sw_stream_device_last_column(mi355sw_handle* h) { return h ? h->d_last_col.p : nullptr; }
+void* mi355sw_stream_device_first_column(mi355sw_handle* h) { return h ? (h->first_col_pinned ? h->p_first_col.p : h->d_first_col.p) : nullptr; }
+void* mi355sw_stream_device_last_column(mi355sw_handle* h) { return h ? h->p_last_col.p : nullptr; }
 
 int mi355sw_stream_poll(mi355sw_handle* h, int32_t* rows_done, int32_t* finished) {
     if (!h || !h->active) return MI355SW_ESTATE;
@@ -472,9 +503,13 @@ int mi355sw_stream_poll(mi355sw_handle* h, int32_t* rows_done, int32_t* finished
 int mi355sw_stream_read_column(mi355sw_handle* h, int32_t row, mi355sw_cell* cells, int32_t len) {
     if (!h || !h->active || !h->sp.want_last_column) return MI355SW_ESTATE;
     if (row < 0 || len < 0 || row + len > h->m) FAIL(h, MI355SW_EINVAL, "read_column range");
-    HIPCHK(h, hipMemcpyAsync(cells, (int2*) h->d_last_col.p + 1 + row, sizeof(int2) * (size_t) len,
-                             hipMemcpyDeviceToHost, h->copy));
-    HIPCHK(h, hipStreamSynchronize(h->copy));
+    // rows below strips_done were written by the kernel (system-scope release) straight into this
+    // pinned buffer: no copy, no queue
+    const int done = __atomic_load_n(&h->h_pinned[0], __ATOMIC_ACQUIRE);
+    long long valid = std::min<long long>((long long) done * h->SH, h->m);
+    if (h->finished) valid = h->m;
+    if (row + len > valid) FAIL(h, MI355SW_EINVAL, "read_column beyond completed rows (%d+%d > %lld)", row, len, valid);
+    memcpy(cells, (mi355sw_cell*) h->p_last_col.p + 1 + row, sizeof(mi355sw_cell) * (size_t) len);
     return MI355SW_OK;
 }
 
@@ -644,7 +679,9 @@ int mi355sw_align_partition(mi355sw_handle* h, const mi355sw_partition* part, co
         int rows_done = 0, fin = 0;
         if ((rc = mi355sw_stream_poll(h, &rows_done, &fin))) { mi355sw_stream_end(h, nullptr, nullptr); return rc; }
         // special rows that are complete (AbstractDiagonalAligner::flushSpecialRows :286-317)
-        while (special_sent < h->n_special) {
+        // (reads of device-resident rows go through the copy stream: only once nothing more has to be
+        //  fed, so that a copy delayed by the running kernel can never starve the kernel of its column)
+        while (special_sent < h->n_special && (fin || fed >= m || orig_col_type == MI355SW_INIT_WITH_ZEROES)) {
             const int dp_row = (special_sent + 1) * h->special_interval_strips * SH;
             if (dp_row > rows_done) break;
             mi355sw_cell c;
