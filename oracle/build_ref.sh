@@ -39,3 +39,15 @@ echo "$list" | xargs -P "${JOBS:-8}" -I{} bash -c 'build_one {}'
 
 $CXX $FLAGS "$HERE/ref_driver.cpp" "$OBJ"/*.o -lpthread -o "$OUT/ref_driver"
 echo "built $OUT/ref_driver"
+
+# End-to-end drop-in binary: the SAME MASA-Core objects driven by the product's IAligner adapter
+# (masa-cudalign_amd/host/Mi355Aligner.cpp -> C ABI -> HIP engine).  Needs libmi355sw.so.
+REPO="$(dirname "$HERE")"
+LIB="$REPO/masa-cudalign_amd/libmi355sw.so"
+if [ -f "$LIB" ]; then
+    $CXX $FLAGS -DUSE_MI355_ALIGNER -I"$REPO/include" -I"$REPO/masa-cudalign_amd/host" \
+        "$HERE/ref_driver.cpp" "$REPO/masa-cudalign_amd/host/Mi355Aligner.cpp" "$OBJ"/*.o \
+        -L"$REPO/masa-cudalign_amd" -lmi355sw -Wl,-rpath,'$ORIGIN/../../masa-cudalign_amd' -lpthread \
+        -o "$OUT/masa_mi355"
+    echo "built $OUT/masa_mi355"
+fi

@@ -40,6 +40,10 @@
 #include "common/Common.hpp"
 #include "common/Job.hpp"
 
+#ifdef USE_MI355_ALIGNER
+#include "Mi355Aligner.hpp"   /* masa-cudalign_amd/host: the product's IAligner adapter (drop-in test) */
+#endif
+
 int stage1(Job* job);
 crosspoint_t stage2(Job* job, int id);
 int stage3(Job* job, int id);
@@ -262,7 +266,12 @@ int main(int argc, char** argv) {
     }
     if (files.size() != 2) { fprintf(stderr, "need two fasta files\n"); return 2; }
 
+#ifdef USE_MI355_ALIGNER
+    Mi355Aligner* aligner = new Mi355Aligner(0, 0, 0);
+    (void) bh; (void) bw;
+#else
     SerialBlockAligner* aligner = new SerialBlockAligner(bh, bw);
+#endif
 
     /* libmasa.cpp:765-806 defaults */
     Job* job = new Job(2);

@@ -1,0 +1,67 @@
+"""GPU (-m gpu): END-TO-END DROP-IN.  oracle/_ref/masa_mi355 is the reference's own MASA-Core (stages 1-6,
+AlignerManager, SRA, crosspoint files -- compiled from /root/reference, unmodified) driven by the product's
+IAligner adapter (masa-cudalign_amd/host/Mi355Aligner.cpp -> C ABI -> HIP engine).  Its outputs must be
+byte-identical to the fixture the reference's CPU aligner produced for the same pair: that covers stage 1
+(SW, special rows on disk), the stage-2/3 re-entry (NW, custom borders, last-column goal matching, early
+stop) and everything downstream."""
+import hashlib
+import os
+import shutil
+import subprocess
+import tempfile
+
+import numpy as np
+import pytest
+
+import __graft_entry__ as graft
+from helpers import load_golden, make_pair, digest
+
+pytestmark = pytest.mark.gpu
+BIN = os.path.join(graft.ROOT, "oracle", "_ref", "masa_mi355")
+G = load_golden()
+
+
+def _run(pkg, oracle, seq, args):
+    if not os.path.exists(BIN):
+        pytest.skip("oracle/_ref/masa_mi355 not prebuilt (needs /root/reference at build time)")
+    s0, s1 = make_pair(pkg, seq)
+    tmp = tempfile.mkdtemp(prefix="masa_dropin_")
+    try:
+        from oracle.binding import _write_fasta, read_ref_work
+        f0, f1 = os.path.join(tmp, "s0.fasta"), os.path.join(tmp, "s1.fasta")
+        _write_fasta(f0, s0, "s0")
+        _write_fasta(f1, s1, "s1")
+        work = os.path.join(tmp, "work")
+        p = subprocess.run([BIN, "--work-dir=" + work] + args + [f0, f1], stdout=subprocess.PIPE,
+                           stderr=subprocess.STDOUT, timeout=600, cwd=tmp)
+        assert p.returncode == 0, p.stdout.decode(errors="replace")[-3000:]
+        return read_ref_work(work, log=p.stdout.decode(errors="replace"))
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def test_full_pipeline_is_byte_identical(pkg, oracle):
+    case = [c for c in G["cases"] if c["name"] == "full_pipeline_3000x2700"][0]
+    out = _run(pkg, oracle, case["seq"], ["--disk-size=200K"])
+    assert list(out["best"]) == case["best"]
+    assert hashlib.sha256(out["alignment_txt"]).hexdigest() == case["alignment_txt_sha256"]
+
+
+@pytest.mark.parametrize("name", ["sw_unrelated_ties_20000x17000", "nw_global_3000x2700", "semiglobal_1to3_2500x2600",
+                                  "sw_with_N_4000x4100"])
+def test_stage1_through_masa_core(pkg, oracle, name):
+    case = [c for c in G["cases"] if c["name"] == name][0]
+    args = [a for a in case["args"] if not a.startswith("--block=")]
+    out = _run(pkg, oracle, case["seq"], args)
+    assert list(out["best"]) == case["best"]
+
+
+def test_special_rows_written_by_masa_core_sra(pkg, oracle):
+    """rows dispatched by the engine and written by the reference's SpecialRowsPartition/SpecialRowFile."""
+    case = [c for c in G["cases"] if c["name"] == "sw_special_rows_20000x9000"][0]
+    out = _run(pkg, oracle, case["seq"], ["--stage-1", "--disk-size=200K", "--no-block-pruning"])
+    assert list(out["best"]) == case["best"]
+    got = {i: a for (d, i), a in out["special_rows"].items()}
+    assert sorted(got) == sorted(int(k) for k in case["special_rows"])
+    for i, a in got.items():
+        assert digest(a) == case["special_rows"][str(i)], i
