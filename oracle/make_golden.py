@@ -70,6 +70,12 @@ CASES = [
          args=["--stage-1", "--no-flush", "--edges=13", "--block=300,300"]),
     dict(name="full_pipeline_3000x2700", seq=dict(kind="related", m=3000, n=2700, cfg=1),
          args=["--disk-size=200K", "--block=128,128"], full=True),
+    # same special-row geometry as the MI355X engine (CUDAlign's 8192-row minimum flush interval,
+    # AbstractDiagonalAligner.cpp:35,:466-478): co-optimal tracebacks then coincide byte for byte
+    dict(name="full_pipeline_3000x2700_b8192", seq=dict(kind="related", m=3000, n=2700, cfg=1),
+         args=["--disk-size=200K", "--block=8192,8192"], full=True),
+    dict(name="full_pipeline_20000x9000_b8192", seq=dict(kind="related", m=20000, n=9000, cfg=4),
+         args=["--disk-size=200K", "--block=8192,8192"], full=True),
 ]
 
 CHAIN = dict(name="sw_chain3_9000x9000", seq=dict(kind="related", m=9000, n=9000, cfg=11), parts=3)
