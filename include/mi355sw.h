@@ -49,6 +49,7 @@ typedef struct { int32_t i0, j0, i1, j1; } mi355sw_partition;
 #define MI355SW_ENOMEM (-4)
 #define MI355SW_ETIMEOUT (-5)   /* a bounded in-kernel spin gave up             */
 #define MI355SW_ESTATE (-6)
+#define MI355SW_EOVERFLOW16 (-7) /* packed 16-bit kernel left its exact range: rerun with force_int32 */
 
 typedef struct mi355sw_handle mi355sw_handle;
 
@@ -62,6 +63,7 @@ typedef struct {
     int64_t max_special_bytes; /* HBM budget for device-resident special rows, 0 = default (8 GiB) */
 } mi355sw_config;
 #define MI355SW_F_FORCE_GENERIC_COMPARE 1   /* raw byte compare kernels even if a profile fits */
+#define MI355SW_F_FORCE_INT32 2             /* never use the packed 16-bit SW kernel */
 
 /* aligner_capabilities_t, M/libmasa/capabilities.hpp:59-225 (same fields, int32 instead of bool) */
 typedef struct {
@@ -111,7 +113,7 @@ typedef struct {
     double total_ms;            /* wall time of the call                                         */
     int32_t kernel_launches;
     int32_t strips, strip_rows, waves;
-    int32_t profile_kernel;     /* 1 = 4-bit profile scoring, 0 = generic byte compare           */
+    int32_t profile_kernel;     /* 1 = 4-bit profile scoring, 0 = generic byte compare, 2 = packed 16-bit */
     int64_t algorithmic_bytes;  /* 17*n*ceil(m/S) + m + 8(n+1)*rows_flushed           */
 } mi355sw_stats;
 
@@ -169,6 +171,7 @@ typedef struct {
     int32_t special_row_interval;       /* rows; 0 = none (rounded up to whole strips like
                                            AbstractDiagonalAligner::isSpecialRow :466-478) */
     int32_t track_best;                 /* mustDispatchScores() */
+    int32_t force_int32;                /* 1: int32 kernel even where the packed 16-bit one applies */
 } mi355sw_stream_params;
 
 int mi355sw_stream_begin(mi355sw_handle* h, const mi355sw_partition* partition, const mi355sw_stream_params* p);

@@ -65,7 +65,7 @@ struct mi355sw_handle {
     int n_match_codes = 0, pad_code = 0;
 
     // work buffers
-    DevBuf d_bus, d_first_col, d_special, d_last_row, d_progress, d_strip_best, d_ctrl;
+    DevBuf d_bus, d_first_col, d_special, d_last_row, d_progress, d_strip_best, d_ctrl, d_kargs;
     PinBuf p_first_col, p_last_col;  // streamed first column / last column (zero-copy)
     bool first_col_pinned = false;
     int* h_pinned = nullptr;        // [0] strips_done (kernel->host) [16] first_col_ready (host->kernel)
@@ -76,6 +76,7 @@ struct mi355sw_handle {
     mi355sw_partition part{};
     mi355sw_stream_params sp{};
     int m = 0, n = 0, R = 8, SH = 512, strips = 0, waves = 0;
+    bool use16 = false;             // packed 16-bit SW kernel selected for the active stream
     int special_interval_strips = 0, n_special = 0;
     long long special_pitch = 0;
     int fed_rows = 0;
@@ -192,7 +193,7 @@ void mi355sw_destroy(mi355sw_handle* h) {
     if (h->p_first_col.p) (void) hipHostFree(h->p_first_col.p);
     if (h->p_last_col.p) (void) hipHostFree(h->p_last_col.p);
     release(h->d_special); release(h->d_last_row); release(h->d_progress);
-    release(h->d_strip_best); release(h->d_ctrl);
+    release(h->d_strip_best); release(h->d_ctrl); release(h->d_kargs);
     if (h->h_pinned) (void) hipHostFree(h->h_pinned);
     if (h->ev0) (void) hipEventDestroy(h->ev0);
     if (h->ev1) (void) hipEventDestroy(h->ev1);
@@ -325,6 +326,7 @@ int mi355sw_stream_begin(mi355sw_handle* h, const mi355sw_partition* part, const
     if ((rc = ensure(h, h->d_progress, sizeof(int) * ((size_t) h->strips + 1)))) return rc;
     if ((rc = ensure(h, h->d_strip_best, sizeof(int4) * (size_t) h->strips))) return rc;
     if ((rc = ensure(h, h->d_ctrl, 256))) return rc;
+    if ((rc = ensure(h, h->d_kargs, sizeof(KernelArgs)))) return rc;
     const bool need_first_col = (p->first_column_init_type != MI355SW_INIT_WITH_ZEROES);
     h->first_col_pinned = need_first_col && p->first_column_init_type == MI355SW_INIT_WITH_CUSTOM_DATA &&
                           p->stream_first_column;
@@ -431,8 +433,15 @@ int mi355sw_stream_begin(mi355sw_handle* h, const mi355sw_partition* part, const
     h->prog_total = h->strips;
 
     HIPCHK(h, hipEventRecord(h->ev0, h->stream));
-    HIPCHK(h, launch_strip_kernel(a, h->R, waves, h->stream, p->recurrence_type == MI355SW_SMITH_WATERMAN,
-                                  h->profile, p->track_best != 0));
+    h->use16 = (p->recurrence_type == MI355SW_SMITH_WATERMAN) && h->profile && !p->force_int32 &&
+               !(h->cfg.flags & MI355SW_F_FORCE_INT32);
+    if (h->use16) {
+        h->stats.profile_kernel = 2;
+        HIPCHK(h, launch_strip_kernel_pk16(a, (KernelArgs*) h->d_kargs.p, h->R / 2, waves, h->stream, p->track_best != 0));
+    } else {
+        HIPCHK(h, launch_strip_kernel(a, (KernelArgs*) h->d_kargs.p, h->R, waves, h->stream, p->recurrence_type == MI355SW_SMITH_WATERMAN,
+                                      h->profile, p->track_best != 0));
+    }
     HIPCHK(h, hipEventRecord(h->ev1, h->stream));
     h->active = true;
     return MI355SW_OK;
@@ -558,6 +567,7 @@ int mi355sw_stream_end(mi355sw_handle* h, mi355sw_score* best, int32_t* n_specia
     int ctrl[64];
     HIPCHK(h, hipMemcpy(ctrl, h->d_ctrl.p, sizeof(ctrl), hipMemcpyDeviceToHost));
     const bool aborted = ctrl[16] != 0;
+    if (ctrl[32] == 16) FAIL(h, MI355SW_EOVERFLOW16, "packed 16-bit kernel left its exact range; rerun with force_int32");
     if (ctrl[32] != 0) FAIL(h, MI355SW_ETIMEOUT, "in-kernel wait timed out (code %d)", ctrl[32]);
     h->strip_best_host.resize((size_t) h->strips);
     HIPCHK(h, hipMemcpy(h->strip_best_host.data(), h->d_strip_best.p, sizeof(int4) * (size_t) h->strips,
@@ -653,13 +663,21 @@ int mi355sw_align_partition(mi355sw_handle* h, const mi355sw_partition* part, co
     }
     if (mg->must_continue && !mg->must_continue(user)) return MI355SW_OK;
 
-    int rc = mi355sw_stream_begin(h, part, &sp);
+    // The packed 16-bit kernel may leave its exact range (reported, never silent).  Nothing is dispatched
+    // to the manager before it has finished cleanly, so that the partition can be re-run with the int32
+    // kernel; partitions that need progressive traffic (streamed first column, last-column matching with
+    // early stop: the stage-2/3 re-entry) go to the int32 kernel directly.
+    bool force32 = (orig_col_type != MI355SW_INIT_WITH_ZEROES) || sp.want_last_column;
+    int rc = MI355SW_OK;
+    for (int attempt = 0; attempt < 2; attempt++) {
+    sp.force_int32 = force32 ? 1 : 0;
+    rc = mi355sw_stream_begin(h, part, &sp);
     if (rc) return rc;
+    const bool deferred = h->use16;
     const int SH = h->SH;
     std::vector<mi355sw_cell> buf((size_t) std::max(SH, 1 << 16));
-    std::vector<mi355sw_cell> col_tail_at_special;   // first-column cell of each special row
     int fed = 0, col_sent = 0, special_sent = 0;
-    bool stopped = false;
+    bool stopped = false, overflow = false;
     std::vector<mi355sw_cell> rowbuf;
     // first-column cells needed later for the leading cell of special/last rows
     std::vector<mi355sw_cell> fc_cells;   // fc_cells[k] = first column cell of DP row (k+1)*SH (or m)
@@ -678,6 +696,12 @@ int mi355sw_align_partition(mi355sw_handle* h, const mi355sw_partition* part, co
         }
         int rows_done = 0, fin = 0;
         if ((rc = mi355sw_stream_poll(h, &rows_done, &fin))) { mi355sw_stream_end(h, nullptr, nullptr); return rc; }
+        if (deferred) {
+            if (!fin) { struct timespec ts = {0, 200000}; nanosleep(&ts, nullptr); continue; }
+            int ctrl[64];
+            HIPCHK(h, hipMemcpy(ctrl, h->d_ctrl.p, sizeof(ctrl), hipMemcpyDeviceToHost));
+            if (ctrl[32] == 16) { overflow = true; break; }
+        }
         // special rows that are complete (AbstractDiagonalAligner::flushSpecialRows :286-317)
         // (reads of device-resident rows go through the copy stream: only once nothing more has to be
         //  fed, so that a copy delayed by the running kernel can never starve the kernel of its column)
@@ -715,6 +739,11 @@ int mi355sw_align_partition(mi355sw_handle* h, const mi355sw_partition* part, co
             nanosleep(&ts, nullptr);
         }
     }
+    if (overflow) {
+        (void) mi355sw_stream_end(h, nullptr, nullptr);   // reports MI355SW_EOVERFLOW16
+        force32 = true;
+        continue;
+    }
     // last row (AbstractDiagonalAligner::flushLastRow :325-353) and last cell (:378-386)
     mi355sw_score best;
     int nsp = 0;
@@ -723,7 +752,9 @@ int mi355sw_align_partition(mi355sw_handle* h, const mi355sw_partition* part, co
         lastrow.resize((size_t) n);
         if ((rc = mi355sw_stream_read_last_row(h, lastrow.data(), 0, n))) { mi355sw_stream_end(h, nullptr, nullptr); return rc; }
     }
-    if ((rc = mi355sw_stream_end(h, &best, &nsp))) return rc;
+    rc = mi355sw_stream_end(h, &best, &nsp);
+    if (rc == MI355SW_EOVERFLOW16 && !force32) { force32 = true; continue; }
+    if (rc) return rc;
     if (stopped) return MI355SW_OK;
     if (mg->must_dispatch_last_row && mg->must_dispatch_last_row(user)) {
         mi355sw_cell c = first_col_tail;
@@ -745,6 +776,8 @@ int mi355sw_align_partition(mi355sw_handle* h, const mi355sw_partition* part, co
         mg->dispatch_score(user, s, -1, -1);
     }
     return MI355SW_OK;
+    }   // attempt
+    return rc;
 }
 
 // AbstractBlockProcessor::processBlock seam (S3): one partition-shaped call with explicit borders.

@@ -42,8 +42,25 @@ struct KernelArgs {
     int* dbg;                    // optional debug words (nullptr in production)
 };
 
-hipError_t launch_strip_kernel(const KernelArgs& a, int rows_per_lane, int grid, hipStream_t stream,
+// The argument block lives in device memory and is read through the constant address space with a
+// readfirstlane'd pointer: every field is then provably wave-uniform (SGPRs, scalar branches).  Passing
+// it by value and taking its address for the noinline strip function made hipcc spill it to scratch,
+// treat every field as divergent and structurize the persistent loop so that lanes left it one by one.
+#if defined(__HIPCC__)
+typedef const __attribute__((address_space(4))) KernelArgs* UniformArgs;
+__device__ __forceinline__ UniformArgs uniform_args(const KernelArgs* p) {
+    const unsigned long long v = (unsigned long long) p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned) v);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned) (v >> 32));
+    return (UniformArgs) (((unsigned long long) hi << 32) | lo);
+}
+#endif
+
+// `dargs` = device copy of the argument block (the launcher uploads `a` into it on `stream`)
+hipError_t launch_strip_kernel(const KernelArgs& a, KernelArgs* dargs, int rows_per_lane, int grid, hipStream_t stream,
                                bool sw, bool profile, bool track);
+// packed 16-bit SW kernel (sw_kernel_pk16.hip): strip height = 128*rows_per_half
+hipError_t launch_strip_kernel_pk16(const KernelArgs& a, KernelArgs* dargs, int rows_per_half, int grid, hipStream_t stream, bool track);
 hipError_t launch_fill_bus(int2* bus, int n, int init_type, int start_offset, hipStream_t stream);
 hipError_t launch_fill_int(int* p, long long count, int value, hipStream_t stream);
 

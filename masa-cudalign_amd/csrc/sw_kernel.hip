@@ -30,7 +30,7 @@
 
 namespace mi355sw {
 
-#define DBG(k, v) do { if (a.dbg != nullptr && lane == 0) st_agent(&a.dbg[k], (v)); } while (0)
+#define DBG(k, v) do { if (a->dbg != nullptr && lane == 0) st_agent(&a->dbg[k], (v)); } while (0)
 
 #define GAP_FIRST 5   // DNA_GAP_OPEN + DNA_GAP_EXT (CUDAligner.hpp:92-98)
 #define GAP_EXT 2
@@ -168,64 +168,66 @@ __device__ __forceinline__ void wave_step(LaneState<R>& st, WaveLds* lds, const 
 }
 
 template <int R, bool SW, bool PROFILE, bool TRACK>
-__device__ __attribute__((noinline)) void process_strip(const KernelArgs& a, const int s, WaveLds* lds, const int lane) {
-    const int n = a.n;
+__device__ __attribute__((noinline)) void process_strip(const KernelArgs* ap, const int s_in, WaveLds* lds, const int lane) {
+    const UniformArgs a = uniform_args(ap);
+    const int s = __builtin_amdgcn_readfirstlane(s_in);
+    const int n = a->n;
     const int SH = 64 * R;
     const int nchunks = (n + 63 + CHUNK - 1) / CHUNK;
-    const int row0 = a.strip_row0 + s * SH;          // first DP row of this strip (0-based)
+    const int row0 = a->strip_row0 + s * SH;          // first DP row of this strip (0-based)
     const int lrow0 = row0 + lane * R;                // first row of this lane
-    const int rows_left = a.m - lrow0;
+    const int rows_left = a->m - lrow0;
     const int nvalid = rows_left < 0 ? 0 : (rows_left > R ? R : rows_left);
-    const int* prog_in = &a.progress[s];              // progress of the strip above
-    int* prog_out = &a.progress[s + 1];
+    const int* prog_in = &a->progress[s];              // progress of the strip above
+    int* prog_out = &a->progress[s + 1];
 
     // which (lane,row) is the row handed to the next strip / flushed as special row
     int emit_lane = 63, emit_row = R - 1;
-    const bool ragged = (row0 + SH > a.m);
+    const bool ragged = (row0 + SH > a->m);
     if (ragged) {
-        const int last = a.m - 1 - row0;              // last valid row inside the strip
+        const int last = a->m - 1 - row0;              // last valid row inside the strip
         emit_lane = last / R;
         emit_row = last - emit_lane * R;
     }
-    const bool last_strip = (row0 + SH >= a.m);
+    const bool last_strip = (row0 + SH >= a->m);
     int2* special = nullptr;
-    if (a.special_interval_strips > 0 && a.special_rows != nullptr) {
-        const int sg = a.strip_index0 + s + 1;       // strips completed once this one ends
-        if (sg % a.special_interval_strips == 0 && (long long) sg * SH < a.m)
-            special = a.special_rows + (long long) (sg / a.special_interval_strips - 1) * a.special_pitch;
+    if (a->special_interval_strips > 0 && a->special_rows != nullptr) {
+        const int sg = a->strip_index0 + s + 1;       // strips completed once this one ends
+        if (sg % a->special_interval_strips == 0 && (long long) sg * SH < a->m)
+            special = a->special_rows + (long long) (sg / a->special_interval_strips - 1) * a->special_pitch;
     }
-    int2* lastrow = (last_strip && a.last_row != nullptr) ? a.last_row : nullptr;
+    int2* lastrow = (last_strip && a->last_row != nullptr) ? a->last_row : nullptr;
 
     // ---- per-lane state from the first column (InitialCellsReader semantics on device) ----
-    if (a.first_col != nullptr && a.first_col_ready != nullptr) {
+    if (a->first_col != nullptr && a->first_col_ready != nullptr) {
         int need = row0 + SH;                         // rows [0,need) of the first column
-        if (need > a.m) need = a.m;
+        if (need > a->m) need = a->m;
         int spins = 0;
-        while (poll_sys(a.first_col_ready) < need && poll_agent(a.abort_flag) == 0 && spins < (1 << 26)) {
+        while (poll_sys(a->first_col_ready) < need && poll_agent(a->abort_flag) == 0 && spins < (1 << 26)) {
             __builtin_amdgcn_s_sleep(32);
             spins++;
         }
-        if (spins >= (1 << 26) && lane == 0) atomicExch(a.error_flag, 2);
+        if (spins >= (1 << 26) && lane == 0) atomicExch(a->error_flag, 2);
     }
     LaneState<R> st;
 #pragma unroll
     for (int r = 0; r < R; r++) {
         int h = 0, e = NEG_INF;
-        if (a.first_col != nullptr) {
+        if (a->first_col != nullptr) {
             const int g = lrow0 + r;
-            if (g < a.m) {
-                const int2 c = ld_sys2(&a.first_col[g + 1]);
+            if (g < a->m) {
+                const int2 c = ld_sys2(&a->first_col[g + 1]);
                 h = c.x; e = c.y;
             }
         }
         st.tl[r] = h - GAP_FIRST;
         st.e[r] = e;
         const int g = lrow0 + r;
-        const int c0 = (g < a.m) ? (int) a.seq0[g] : a.pad_code;
+        const int c0 = (g < a->m) ? (int) a->seq0[g] : a->pad_code;
         if (PROFILE) {
             // nibble k = score(c0, code k) + 5 : 6 on match, 2 otherwise; pad/foreign codes never match
             u32 p = 0x22222222u;
-            if (c0 < a.n_match_codes) p += (4u << (4 * c0));
+            if (c0 < a->n_match_codes) p += (4u << (4 * c0));
             st.prof[r] = (int) p;
         } else {
             st.prof[r] = c0;
@@ -233,7 +235,7 @@ __device__ __attribute__((noinline)) void process_strip(const KernelArgs& a, con
     }
     {
         int hd = 0;
-        if (a.first_col != nullptr && lrow0 <= a.m) hd = ld_sys2(&a.first_col[lrow0]).x;
+        if (a->first_col != nullptr && lrow0 <= a->m) hd = ld_sys2(&a->first_col[lrow0]).x;
         st.tup_prev = hd - GAP_FIRST;
     }
     st.tbot = NEG_INF; st.fbot = NEG_INF;
@@ -254,14 +256,14 @@ __device__ __attribute__((noinline)) void process_strip(const KernelArgs& a, con
                     __builtin_amdgcn_s_sleep(2);
                     spins++;
                 }
-                if (spins >= (1 << 24) && lane == 0) atomicExch(a.error_flag, 1);
+                if (spins >= (1 << 24) && lane == 0) atomicExch(a->error_flag, 1);
             }
             const int col = col0 + lane;
             int2 hf = make_int2(0, NEG_INF);
             unsigned char code = 0;
             if (col < n) {
-                hf = ld_agent2(&a.bus[col]);
-                code = a.seq1[col];
+                hf = ld_agent2(&a->bus[col]);
+                code = a->seq1[col];
             }
             // shift the seq1 window: [64,128) -> [0,64), then the new chunk
             const unsigned char prev = lds->c1[CHUNK + lane];
@@ -301,7 +303,7 @@ __device__ __attribute__((noinline)) void process_strip(const KernelArgs& a, con
             const int col = col0 - emit_lane + lane;
             if (col >= 0 && col < n) {
                 const int2 hf = make_int2(tf.x + GAP_FIRST, tf.y);
-                st_agent2(&a.bus[col], hf);
+                st_agent2(&a->bus[col], hf);
                 if (special != nullptr) special[col] = hf;
                 if (lastrow != nullptr) lastrow[col] = hf;
             }
@@ -316,11 +318,11 @@ __device__ __attribute__((noinline)) void process_strip(const KernelArgs& a, con
 
     DBG(3, 40);
     // ---- strip epilogue: last column, best score ----
-    if (a.last_col != nullptr) {
+    if (a->last_col != nullptr) {
 #pragma unroll
         for (int r = 0; r < R; r++) {
             const int g = lrow0 + r;
-            if (g < a.m) a.last_col[g + 1] = make_int2(st.tl[r] + GAP_FIRST, st.e[r]);
+            if (g < a->m) a->last_col[g + 1] = make_int2(st.tl[r] + GAP_FIRST, st.e[r]);
         }
     }
     if (TRACK) {
@@ -342,48 +344,61 @@ __device__ __attribute__((noinline)) void process_strip(const KernelArgs& a, con
             int4 rec;
             rec.x = (bj >= 0) ? bt + GAP_FIRST : NEG_INF;
             rec.y = bi; rec.z = bj; rec.w = 1;
-            a.strip_best[s] = rec;
+            a->strip_best[s] = rec;
         }
         __builtin_amdgcn_wave_barrier();
     }
 }
 
+// Ordered completion: strips_done == s+1 means strips 0..s are complete and their last-column /
+// special-row / best records are visible to the host (system scope).  A separate noinline function on
+// purpose: with a lane-0-only `if` as the last statement of the persistent loop, hipcc's structurizer
+// moved lane 0 out of the loop body and sent lanes 1..63 through the next iteration on their own
+// (readfirstlane then read their zero-initialised ticket: strip 0 was processed twice and never published).
+__device__ __attribute__((noinline)) void complete_strip(const KernelArgs* ap, const int s_in, const int lane) {
+    const UniformArgs a = uniform_args(ap);
+    const int s = __builtin_amdgcn_readfirstlane(s_in);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    int spins = 0;
+    while (poll_agent(a->strips_done_dev) != s && spins < (1 << 24)) {
+        __builtin_amdgcn_s_sleep(8);
+        spins++;
+    }
+    if (lane == 0) {
+        if (spins >= (1 << 24)) atomicExch(a->error_flag, 3);
+        if (a->strips_done_host != nullptr)
+            __hip_atomic_store(a->strips_done_host, s + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        st_agent(a->strips_done_dev, s + 1);
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
+// Claim the next strip: ordered tickets => forward progress for any grid size.
+__device__ __attribute__((noinline)) int claim_strip(const KernelArgs* ap, const int lane) {
+    const UniformArgs a = uniform_args(ap);
+    int s = 0;
+    if (lane == 0) s = atomicAdd(a->ticket, 1);
+    return __builtin_amdgcn_readfirstlane(s);
+}
+
 template <int R, bool SW, bool PROFILE, bool TRACK>
-__global__ void __launch_bounds__(64) sw_strip_kernel(KernelArgs a) {
+__global__ void __launch_bounds__(64) sw_strip_kernel(const KernelArgs* __restrict__ ap) {
     __shared__ WaveLds lds_store;
     WaveLds* lds = &lds_store;
     const int lane = threadIdx.x;
-    const int n = a.n;
-
+    const UniformArgs a = uniform_args(ap);
+    const int num_strips = a->num_strips;
     for (;;) {
-        // ---- claim the next strip (ordered tickets => forward progress) ----
-        int s = 0;
-        if (lane == 0) s = atomicAdd(a.ticket, 1);
-        s = __builtin_amdgcn_readfirstlane(s);
-        DBG(0, 100 + s);
-        if (s >= a.num_strips) break;
-        if (poll_agent(a.abort_flag) != 0) {
+        const int s = __builtin_amdgcn_readfirstlane(claim_strip(ap, lane));
+        if (s >= num_strips) break;
+        if (poll_agent(a->abort_flag) != 0) {
             // publish completion so that followers do not spin forever
-            if (lane == 0) st_agent(&a.progress[s + 1], n);
+            if (lane == 0) st_agent(&a->progress[s + 1], a->n);
+            __builtin_amdgcn_wave_barrier();
         } else {
-            process_strip<R, SW, PROFILE, TRACK>(a, s, lds, lane);
+            process_strip<R, SW, PROFILE, TRACK>(ap, s, lds, lane);
         }
-        DBG(3, 50);
-        // ---- ordered completion: strips_done == s+1 means strips 0..s are complete and their
-        //      last-column / special-row / best records are visible to the host (system scope) ----
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
-        int spins = 0;
-        while (poll_agent(a.strips_done_dev) != s && spins < (1 << 24)) {
-            __builtin_amdgcn_s_sleep(8);
-            spins++;
-        }
-        if (lane == 0) {
-            if (spins >= (1 << 24)) atomicExch(a.error_flag, 3);
-            if (a.strips_done_host != nullptr)
-                __hip_atomic_store(a.strips_done_host, s + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-            st_agent(a.strips_done_dev, s + 1);
-        }
-        DBG(3, 54);
+        complete_strip(ap, s, lane);
     }
 }
 
@@ -404,7 +419,7 @@ __global__ void fill_int_kernel(int* p, long long count, int value) {
 }
 
 template <int R>
-static hipError_t launch_r(const KernelArgs& a, int grid, hipStream_t stream, bool sw, bool profile, bool track) {
+static hipError_t launch_r(const KernelArgs* a, int grid, hipStream_t stream, bool sw, bool profile, bool track) {
 #define LAUNCH(SWV, PRV, TRV) \
     hipLaunchKernelGGL((sw_strip_kernel<R, SWV, PRV, TRV>), dim3(grid), dim3(64), 0, stream, a)
     if (sw) {
@@ -418,12 +433,16 @@ static hipError_t launch_r(const KernelArgs& a, int grid, hipStream_t stream, bo
     return hipGetLastError();
 }
 
-hipError_t launch_strip_kernel(const KernelArgs& a, int rows_per_lane, int grid, hipStream_t stream,
+hipError_t launch_strip_kernel(const KernelArgs& a, KernelArgs* dargs, int rows_per_lane, int grid, hipStream_t stream,
                                bool sw, bool profile, bool track) {
+    hipError_t e = hipMemcpyAsync(dargs, &a, sizeof(KernelArgs), hipMemcpyHostToDevice, stream);
+    if (e != hipSuccess) return e;
+    e = hipStreamSynchronize(stream);      // `a` is a host temporary
+    if (e != hipSuccess) return e;
     switch (rows_per_lane) {
-    case 4: return launch_r<4>(a, grid, stream, sw, profile, track);
-    case 8: return launch_r<8>(a, grid, stream, sw, profile, track);
-    case 16: return launch_r<16>(a, grid, stream, sw, profile, track);
+    case 4: return launch_r<4>(dargs, grid, stream, sw, profile, track);
+    case 8: return launch_r<8>(dargs, grid, stream, sw, profile, track);
+    case 16: return launch_r<16>(dargs, grid, stream, sw, profile, track);
     default: return hipErrorInvalidValue;
     }
 }

@@ -1,0 +1,469 @@
+// MI355X (gfx950) Stage-1 SW strip kernel, PACKED 16-BIT form: two DP cells per VALU instruction.
+//
+// Why: a wave64 int32 VALU op issues once per 4 cycles per SIMD on this chip whatever the occupancy
+// (tools/micro_valu.hip), so the int32 kernel (sw_kernel.hip, ~10.8 ops/cell) is pinned at its VALU
+// ceiling.  v_pk_{add,max}_i16 / v_pk_min_u16 issue at the same rate and carry two cells.
+//
+// Geometry: every lane owns TWO row blocks of R rows, packed lo/hi in each 32-bit register: the LO
+// block (rows 2kR..2kR+R-1 of the strip) and the HI block (the next R rows), HI running ONE column behind
+// LO.  The wave is a 128-stage systolic array ("virtual lane" v = 2*lane+half is v columns behind virtual
+// lane 0): the LO block receives the bottom (T,F) of the previous lane's HI block by DPP wave_shr:1, the HI
+// block receives its own lane's LO bottom of the previous step; one v_alignbit_b32 merges the two.
+// Strip height = 128*R rows.
+//
+// Arithmetic (T = H-3 domain, exact restatement of CPUBlockProcessor.cpp:66-93 for SW):
+//   x = mask0[r] & mask1        one-hot base masks (bit 2+code), both halves at once
+//   y = pk_min_u16(x, 4)        = 4 on match, 0 otherwise        (score+3)
+//   E = sat(pk_max(TL,E) - 2) ; F = sat(pk_max(upT,upF) - 2)     (max(Hl-5,E-2) = max(Tl,E)-2)
+//   H = pk_max(pk_max(pk_max(diag+y, E), F), Z)                  Z = T-domain zero level
+//   T = H - 3
+// 11 packed ops per 2 cells (+1 for the running maximum).  Values are 16-bit relative to a wave-uniform
+// bias (0 in this round): a per-chunk guard on the running maximum reports MI355SW overflow long before a
+// wrap is possible (growth per chunk <= 64), and the host falls back to the int32 kernel.  -INF borders
+// saturate at -32768 and stay there (saturating -2).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "sw_kernel.h"
+
+namespace mi355sw {
+
+#define DBG16(k, v) do { if (a->dbg != nullptr && lane == 0) __hip_atomic_store(&a->dbg[k], (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while (0)
+
+#define NEG_INF (-999999999)
+#define T_OFF 3            // T = H - 3
+#define GUARD16 30000      // chunk maximum above this => overflow report (wrap needs 32767)
+
+typedef unsigned int u32;
+typedef short s2 __attribute__((ext_vector_type(2)));
+typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ s2 as_s2(int x) { return __builtin_bit_cast(s2, x); }
+__device__ __forceinline__ int as_i(s2 x) { return __builtin_bit_cast(int, x); }
+__device__ __forceinline__ s2 pmax(s2 a, s2 b) { return __builtin_elementwise_max(a, b); }
+__device__ __forceinline__ s2 padd_sat(s2 a, s2 b) { return __builtin_elementwise_add_sat(a, b); }
+__device__ __forceinline__ s2 splat(int v) { s2 r = {(short) v, (short) v}; return r; }
+__device__ __forceinline__ int pack(int lo, int hi) { return (lo & 0xffff) | (hi << 16); }
+__device__ __forceinline__ int clamp16(int x) { return x < -32768 ? -32768 : (x > 32767 ? 32767 : x); }
+__device__ __forceinline__ int lo16(int x) { return __builtin_amdgcn_sbfe(x, 0, 16); }
+__device__ __forceinline__ int hi16(int x) { return x >> 16; }
+
+__device__ __forceinline__ int wave_shr1_16(int old, int src) {
+    return __builtin_amdgcn_update_dpp(old, src, 0x138, 0xf, 0xf, false);
+}
+__device__ __forceinline__ int poll_agent16(const int* p) {
+    return __builtin_amdgcn_readfirstlane(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ int poll_sys16(const int* p) {
+    return __builtin_amdgcn_readfirstlane(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+}
+__device__ __forceinline__ void st_agent16(int* p, int v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ int2 ld_agent2_16(const int2* p) {
+    unsigned long long x = __hip_atomic_load((const unsigned long long*) p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return make_int2((int) (u32) x, (int) (u32) (x >> 32));
+}
+__device__ __forceinline__ int2 ld_sys2_16(const int2* p) {
+    unsigned long long x = __hip_atomic_load((const unsigned long long*) p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    return make_int2((int) (u32) x, (int) (u32) (x >> 32));
+}
+__device__ __forceinline__ void st_agent2_16(int2* p, int2 v) {
+    unsigned long long x = ((unsigned long long) (u32) v.y << 32) | (u32) v.x;
+    __hip_atomic_store((unsigned long long*) p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+enum { WIN = 128 };   // seq1 window: 128 columns of history in front of the 64-column chunk
+
+struct __attribute__((aligned(16))) WaveLds16 {
+    int2 in_tf[CHUNK + 1];      // (T16<<16, F16<<16) of the row above (value in the HIGH half: DPP `old` of lane 0)
+    int2 out_tf[CHUNK];         // packed (T,F) words of the emit lane, one per step
+    int c1w[WIN + CHUNK + 8];   // per column j: mask(j) | mask(j-1)<<16
+    int red[3 * 64];
+};
+
+template <int R>
+struct Lane16 {
+    s2 TL[R];       // T of the cell to the left      (lo: LO block row r, hi: HI block row r)
+    s2 E[R];        // E of the cell to the left
+    int M0[R];      // one-hot base masks of the two rows
+    s2 tup_prev;    // T of (row above the block, previous column)
+    s2 tbot, fbot;  // bottoms produced at the previous step
+    int best_t, best_r, best_j;   // best T (true, 32-bit), row index inside the lane (0..2R-1), column
+};
+
+template <int R, bool MASKED, bool TRACK, bool EMIT_ANY>
+__device__ __forceinline__ void wave_step16(Lane16<R>& st, WaveLds16* lds, const int u, const int lane,
+                                            const int jl /* LO column of this lane at u=0 */, const int n,
+                                            const int nvalid_lo, const int nvalid_hi, const int emit_lane,
+                                            const int emit_row, const s2 Z, const int bias, int2& feed_io, int& c1_io,
+                                            s2& chunk_max) {
+    const int2 feed = feed_io;
+    const int c1p = c1_io;
+    feed_io = lds->in_tf[u + 1];
+    c1_io = lds->c1w[WIN + u + 1 - 2 * lane];
+    // hand-off: LO <- previous lane's HI bottom (DPP), HI <- own LO bottom; lane 0 LO <- bus feed
+    const int dT = wave_shr1_16(feed.x, as_i(st.tbot));
+    const int dF = wave_shr1_16(feed.y, as_i(st.fbot));
+    const s2 tup = as_s2(__builtin_amdgcn_alignbit(as_i(st.tbot), dT, 16));
+    s2 upT = tup;
+    s2 upF = as_s2(__builtin_amdgcn_alignbit(as_i(st.fbot), dF, 16));
+    s2 diag = st.tup_prev;
+
+    int vmask = -1;
+    if (MASKED) {
+        const int j = jl + u;                                  // LO column; HI is at j-1
+        const bool vlo = (u32) j < (u32) n;
+        const bool vhi = (u32) (j - 1) < (u32) n;
+        vmask = (vlo ? 0xffff : 0) | (vhi ? 0xffff0000 : 0);
+    }
+    const s2 m2 = splat(-2), m3 = splat(-T_OFF);
+    const us2 four = {4, 4};
+    s2 t_emit = splat(0), f_emit = splat(0);
+    s2 ms = splat(-32768);
+    s2 newT[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const int x = st.M0[r] & c1p;
+        const us2 y = __builtin_elementwise_min(__builtin_bit_cast(us2, x), four);
+        s2 Ev = padd_sat(pmax(st.TL[r], st.E[r]), m2);
+        s2 Fv = padd_sat(pmax(upT, upF), m2);
+        const s2 v = diag + __builtin_bit_cast(s2, y);
+        const s2 H = pmax(pmax(pmax(v, Ev), Fv), Z);
+        s2 T = H + m3;
+        diag = st.TL[r];
+        if (MASKED) {
+            T = as_s2((as_i(T) & vmask) | (as_i(st.TL[r]) & ~vmask));
+            Ev = as_s2((as_i(Ev) & vmask) | (as_i(st.E[r]) & ~vmask));
+        }
+        st.TL[r] = T;
+        st.E[r] = Ev;
+        newT[r] = T;
+        upT = T;
+        upF = Fv;
+        ms = pmax(ms, T);
+        if (EMIT_ANY) {
+            t_emit = (r == emit_row) ? T : t_emit;
+            f_emit = (r == emit_row) ? Fv : f_emit;
+        }
+    }
+    if (MASKED) {
+        st.tup_prev = as_s2((as_i(tup) & vmask) | (as_i(st.tup_prev) & ~vmask));
+        st.tbot = as_s2((as_i(upT) & vmask) | (as_i(st.tbot) & ~vmask));
+        st.fbot = as_s2((as_i(upF) & vmask) | (as_i(st.fbot) & ~vmask));
+    } else {
+        st.tup_prev = tup;
+        st.tbot = upT;
+        st.fbot = upF;
+    }
+    if (!EMIT_ANY) { t_emit = upT; f_emit = upF; }
+    if (lane == emit_lane) lds->out_tf[u] = make_int2(as_i(t_emit), as_i(f_emit));
+    chunk_max = pmax(chunk_max, ms);
+
+    if (TRACK) {
+        // cheap per-step test on max(lo,hi); rare exact path keeps the canonical (max, min i, min j) cell
+        const int mi = as_i(ms);
+        const int m = max(lo16(mi), hi16(mi)) + bias;
+        if (__any(m >= st.best_t)) {
+            const int j = jl + u;
+#pragma unroll
+            for (int half = 0; half < 2; half++) {
+                const int nv = half ? nvalid_hi : nvalid_lo;
+                const bool hv = MASKED ? (((vmask >> (16 * half)) & 1) != 0) : true;
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    const int w = as_i(newT[r]);
+                    const int t = (half ? hi16(w) : lo16(w)) + bias;
+                    const int rr = half * R + r;
+                    const bool upd = hv && (r < nv) && ((t > st.best_t) || (t == st.best_t && rr < st.best_r));
+                    st.best_t = upd ? t : st.best_t;
+                    st.best_r = upd ? rr : st.best_r;
+                    st.best_j = upd ? (j - half) : st.best_j;
+                }
+            }
+        }
+    }
+}
+
+template <int R, bool TRACK>
+__device__ __attribute__((noinline)) void process_strip16(const KernelArgs* ap, const int s_in, WaveLds16* lds, const int lane) {
+    const UniformArgs a = uniform_args(ap);
+    const int s = __builtin_amdgcn_readfirstlane(s_in);
+    const int n = a->n;
+    const int SH = 128 * R;
+    const int nchunks = (n + 127 + CHUNK - 1) / CHUNK;
+    const int bias = 0;                                   // wave-uniform 16-bit bias (fixed this round)
+    const s2 Z = splat(clamp16(0 - bias));                // H-domain zero level of the SW clamp
+
+    const int row0 = a->strip_row0 + s * SH;
+    const int lrow_lo = row0 + (2 * lane) * R;            // first row of the LO block
+    const int lrow_hi = lrow_lo + R;                      // first row of the HI block
+    int nvalid_lo = a->m - lrow_lo; nvalid_lo = nvalid_lo < 0 ? 0 : (nvalid_lo > R ? R : nvalid_lo);
+    int nvalid_hi = a->m - lrow_hi; nvalid_hi = nvalid_hi < 0 ? 0 : (nvalid_hi > R ? R : nvalid_hi);
+    const int* prog_in = &a->progress[s];
+    int* prog_out = &a->progress[s + 1];
+
+    // emitting virtual lane / row: the strip's bottom row, or DP row m-1 for the ragged last strip
+    int emit_v = 127, emit_row = R - 1;
+    const bool ragged = (row0 + SH > a->m);
+    if (ragged) {
+        const int last = a->m - 1 - row0;
+        emit_v = last / R;
+        emit_row = last - emit_v * R;
+    }
+    const int emit_lane = emit_v >> 1, emit_half = emit_v & 1;
+    const bool last_strip = (row0 + SH >= a->m);
+    int2* special = nullptr;
+    if (a->special_interval_strips > 0 && a->special_rows != nullptr) {
+        const int sg = a->strip_index0 + s + 1;
+        if (sg % a->special_interval_strips == 0 && (long long) sg * SH < a->m)
+            special = a->special_rows + (long long) (sg / a->special_interval_strips - 1) * a->special_pitch;
+    }
+    int2* lastrow = (last_strip && a->last_row != nullptr) ? a->last_row : nullptr;
+
+    bool overflow = false;
+    // ---- first column ----
+    if (a->first_col != nullptr && a->first_col_ready != nullptr) {
+        int need = row0 + SH;
+        if (need > a->m) need = a->m;
+        int spins = 0;
+        while (poll_sys16(a->first_col_ready) < need && poll_agent16(a->abort_flag) == 0 && spins < (1 << 26)) {
+            __builtin_amdgcn_s_sleep(32);
+            spins++;
+        }
+        if (spins >= (1 << 26) && lane == 0) atomicExch(a->error_flag, 2);
+    }
+    Lane16<R> st;
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        int t[2], e[2], mk[2];
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+            const int g = (half ? lrow_hi : lrow_lo) + r;
+            int h = 0, ee = NEG_INF;
+            if (a->first_col != nullptr && g < a->m) {
+                const int2 c = ld_sys2_16(&a->first_col[g + 1]);
+                h = c.x; ee = c.y;
+            }
+            if (h - T_OFF - bias > GUARD16) overflow = true;
+            t[half] = clamp16(h - T_OFF - bias);
+            e[half] = clamp16(ee - bias);
+            const int c0 = (g < a->m) ? (int) a->seq0[g] : a->pad_code;
+            mk[half] = (c0 < a->n_match_codes) ? (4 << c0) : 0;
+        }
+        st.TL[r] = as_s2(pack(t[0], t[1]));
+        st.E[r] = as_s2(pack(e[0], e[1]));
+        st.M0[r] = pack(mk[0], mk[1]);
+    }
+    {
+        int hd[2];
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+            const int g0 = half ? lrow_hi : lrow_lo;
+            int h = 0;
+            if (a->first_col != nullptr && g0 <= a->m) h = ld_sys2_16(&a->first_col[g0]).x;
+            hd[half] = clamp16(h - T_OFF - bias);
+        }
+        st.tup_prev = as_s2(pack(hd[0], hd[1]));
+    }
+    st.tbot = splat(-32768);
+    st.fbot = splat(-32768);
+    st.best_t = NEG_INF; st.best_r = 2 * R; st.best_j = -1;
+
+    // seq1 window starts empty
+    lds->c1w[lane] = 0; lds->c1w[64 + lane] = 0; lds->c1w[128 + lane] = 0;
+    if (lane < 8) lds->c1w[192 + lane] = 0;
+
+    DBG16(1, 1);
+    for (int c = 0; c < nchunks; c++) {
+        const int col0 = c * CHUNK;
+        DBG16(2, c); DBG16(3, 10);
+        // (1) stage the input chunk
+        {
+            int need = col0 + CHUNK;
+            if (need > n) need = n;
+            if (col0 < n) {
+                int spins = 0;
+                while (poll_agent16(prog_in) < need && spins < (1 << 24)) {
+                    __builtin_amdgcn_s_sleep(2);
+                    spins++;
+                }
+                if (spins >= (1 << 24) && lane == 0) atomicExch(a->error_flag, 1);
+            }
+            const int col = col0 + lane;
+            int2 hf = make_int2(0, NEG_INF);
+            int code = 255, codep = 255;
+            if (col < n) {
+                hf = ld_agent2_16(&a->bus[col]);
+                code = a->seq1[col] >> 2;               // seq1 holds code*4 (shift form of the int32 kernel)
+            }
+            if (col >= 1 && col - 1 < n) codep = a->seq1[col - 1] >> 2;
+            const int mk = (code < a->n_match_codes) ? (4 << code) : 0;
+            const int mkp = (codep < a->n_match_codes) ? (4 << codep) : 0;
+            if (hf.x - T_OFF - bias > GUARD16) overflow = true;
+            // shift the window by one chunk, then append
+            const int w0 = lds->c1w[64 + lane];
+            const int w1 = lds->c1w[128 + lane];
+            lds->c1w[lane] = w0;
+            lds->c1w[64 + lane] = w1;
+            lds->c1w[128 + lane] = mk | (mkp << 16);
+            lds->in_tf[lane] = make_int2(clamp16(hf.x - T_OFF - bias) << 16, clamp16(hf.y - bias) << 16);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+        DBG16(3, 20);
+        // (2) 64 systolic steps
+        const int jl = col0 - 2 * lane;
+        const bool masked = (col0 - 127 < 0) || (col0 + CHUNK - 1 >= n);
+        int2 feed = lds->in_tf[0];
+        int c1 = lds->c1w[WIN - 2 * lane];
+        s2 cmax = splat(-32768);
+        if (ragged) {
+#pragma unroll 2
+            for (int u = 0; u < CHUNK; u++)
+                wave_step16<R, true, TRACK, true>(st, lds, u, lane, jl, n, nvalid_lo, nvalid_hi, emit_lane, emit_row, Z, bias, feed, c1, cmax);
+        } else if (masked) {
+#pragma unroll 2
+            for (int u = 0; u < CHUNK; u++)
+                wave_step16<R, true, TRACK, false>(st, lds, u, lane, jl, n, nvalid_lo, nvalid_hi, 63, R - 1, Z, bias, feed, c1, cmax);
+        } else {
+#pragma unroll 2
+            for (int u = 0; u < CHUNK; u++)
+                wave_step16<R, false, TRACK, false>(st, lds, u, lane, jl, n, nvalid_lo, nvalid_hi, 63, R - 1, Z, bias, feed, c1, cmax);
+        }
+        DBG16(3, 30);
+        // 16-bit range guard (wave-uniform)
+        {
+            const int cm = as_i(cmax);
+            if (max(lo16(cm), hi16(cm)) > GUARD16) overflow = true;
+        }
+        // (3) output chunk: columns col0-emit_v .. col0-emit_v+63
+        {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const int2 tf = lds->out_tf[lane];
+            const int col = col0 - emit_v + lane;
+            if (col >= 0 && col < n) {
+                const int t16 = emit_half ? hi16(tf.x) : lo16(tf.x);
+                const int f16 = emit_half ? hi16(tf.y) : lo16(tf.y);
+                // -32768 is the sticky image of -INF (only border rows can carry it)
+                const int2 hf = make_int2(t16 + T_OFF + bias, f16 == -32768 ? NEG_INF : f16 + bias);
+                st_agent2_16(&a->bus[col], hf);
+                if (special != nullptr) special[col] = hf;
+                if (lastrow != nullptr) lastrow[col] = hf;
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            int done = col0 - emit_v + CHUNK;
+            if (done > n) done = n;
+            if (done < 0) done = 0;
+            if (lane == 0) st_agent16(prog_out, done);
+        }
+    }
+
+    if (__any(overflow)) {
+        if (lane == 0) { atomicExch(a->error_flag, 16); st_agent16(a->abort_flag, 1); }
+    }
+    DBG16(3, 40);
+    // ---- strip epilogue ----
+    if (a->last_col != nullptr) {
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const int g = (half ? lrow_hi : lrow_lo) + r;
+                if (g < a->m) {
+                    const int t16 = half ? hi16(as_i(st.TL[r])) : lo16(as_i(st.TL[r]));
+                    const int e16 = half ? hi16(as_i(st.E[r])) : lo16(as_i(st.E[r]));
+                    a->last_col[g + 1] = make_int2(t16 + T_OFF + bias, e16 == -32768 ? NEG_INF : e16 + bias);
+                }
+            }
+        }
+    }
+    if (TRACK) {
+        lds->red[lane] = st.best_t;
+        lds->red[64 + lane] = (st.best_j >= 0) ? (lrow_lo + st.best_r) : 0x7fffffff;   // LO rows then HI rows are consecutive
+        lds->red[128 + lane] = st.best_j;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (lane == 0) {
+            int bt = NEG_INF, bi = 0x7fffffff, bj = -1;
+            for (int k = 0; k < 64; k++) {
+                const int t = lds->red[k], i = lds->red[64 + k], j = lds->red[128 + k];
+                if (j >= 0 && (t > bt || (t == bt && (i < bi || (i == bi && j < bj))))) { bt = t; bi = i; bj = j; }
+            }
+            int4 rec;
+            rec.x = (bj >= 0) ? bt + T_OFF : NEG_INF;
+            rec.y = bi; rec.z = bj; rec.w = 1;
+            a->strip_best[s] = rec;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// see sw_kernel.hip: claim/complete are separate noinline functions so that the persistent loop body
+// contains no lane-divergent statement for the structurizer to peel.
+__device__ __attribute__((noinline)) void complete_strip16(const KernelArgs* ap, const int s_in, const int lane) {
+    const UniformArgs a = uniform_args(ap);
+    const int s = __builtin_amdgcn_readfirstlane(s_in);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    int spins = 0;
+    while (poll_agent16(a->strips_done_dev) != s && spins < (1 << 24)) {
+        __builtin_amdgcn_s_sleep(8);
+        spins++;
+    }
+    if (lane == 0) {
+        if (spins >= (1 << 24)) atomicExch(a->error_flag, 3);
+        if (a->strips_done_host != nullptr)
+            __hip_atomic_store(a->strips_done_host, s + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        st_agent16(a->strips_done_dev, s + 1);
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __attribute__((noinline)) int claim_strip16(const KernelArgs* ap, const int lane) {
+    const UniformArgs a = uniform_args(ap);
+    int s = 0;
+    if (lane == 0) s = atomicAdd(a->ticket, 1);
+    return __builtin_amdgcn_readfirstlane(s);
+}
+
+template <int R, bool TRACK>
+__global__ void __launch_bounds__(64) sw_strip_kernel_pk16(const KernelArgs* __restrict__ ap) {
+    __shared__ WaveLds16 lds_store;
+    WaveLds16* lds = &lds_store;
+    const int lane = threadIdx.x;
+    const UniformArgs a = uniform_args(ap);
+    const int num_strips = a->num_strips;
+    for (;;) {
+        const int s = __builtin_amdgcn_readfirstlane(claim_strip16(ap, lane));
+        if (s >= num_strips) break;
+        if (poll_agent16(a->abort_flag) != 0) {
+            if (lane == 0) st_agent16(&a->progress[s + 1], a->n);
+            __builtin_amdgcn_wave_barrier();
+        } else {
+            process_strip16<R, TRACK>(ap, s, lds, lane);
+        }
+        complete_strip16(ap, s, lane);
+    }
+}
+
+hipError_t launch_strip_kernel_pk16(const KernelArgs& a, KernelArgs* dargs, int rows_per_half, int grid, hipStream_t stream, bool track) {
+    hipError_t e = hipMemcpyAsync(dargs, &a, sizeof(KernelArgs), hipMemcpyHostToDevice, stream);
+    if (e != hipSuccess) return e;
+    e = hipStreamSynchronize(stream);
+    if (e != hipSuccess) return e;
+#define LAUNCH16(RV, TRV) hipLaunchKernelGGL((sw_strip_kernel_pk16<RV, TRV>), dim3(grid), dim3(64), 0, stream, (const KernelArgs*) dargs)
+    switch (rows_per_half) {
+    case 2: if (track) LAUNCH16(2, true); else LAUNCH16(2, false); break;
+    case 4: if (track) LAUNCH16(4, true); else LAUNCH16(4, false); break;
+    case 8: if (track) LAUNCH16(8, true); else LAUNCH16(8, false); break;
+    default: return hipErrorInvalidValue;
+    }
+#undef LAUNCH16
+    return hipGetLastError();
+}
+
+}  // namespace mi355sw

@@ -19,7 +19,7 @@ INF = 999999999
 NEEDLEMAN_WUNSCH, SMITH_WATERMAN = 0, 1
 INIT_WITH_ZEROES, INIT_WITH_GAPS, INIT_WITH_CUSTOM_DATA, INIT_WITH_GAPS_OPENED = 0, 1, 2, 3
 
-ERRORS = {-1: "EINVAL", -2: "EHIP", -3: "ENOGPU", -4: "ENOMEM", -5: "ETIMEOUT", -6: "ESTATE"}
+ERRORS = {-1: "EINVAL", -2: "EHIP", -3: "ENOGPU", -4: "ENOMEM", -5: "ETIMEOUT", -6: "ESTATE", -7: "EOVERFLOW16"}
 
 
 class AlignerError(RuntimeError):
@@ -87,7 +87,7 @@ class StreamParams(C.Structure):
                 ("stream_first_column", C.c_int32),
                 ("first_column", C.c_void_p),
                 ("want_last_column", C.c_int32), ("want_last_row", C.c_int32),
-                ("special_row_interval", C.c_int32), ("track_best", C.c_int32)]
+                ("special_row_interval", C.c_int32), ("track_best", C.c_int32), ("force_int32", C.c_int32)]
 
 
 _VP = C.c_void_p
@@ -131,7 +131,7 @@ _lib = None
 def build_library(force=False):
     """Compile csrc/ for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
     src = os.path.join(HERE, "csrc")
-    deps = [os.path.join(src, f) for f in ("runtime.cpp", "sw_kernel.hip", "sw_kernel.h")] + [INCLUDE_PATH]
+    deps = [os.path.join(src, f) for f in ("runtime.cpp", "sw_kernel.hip", "sw_kernel_pk16.hip", "sw_kernel.h")] + [INCLUDE_PATH]
     if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
         return LIB_PATH
     subprocess.check_call(["make", "-C", src], stdout=subprocess.DEVNULL)
@@ -295,7 +295,8 @@ class MI355Aligner:
     def streamBegin(self, partition, recurrence_type=SMITH_WATERMAN, first_row_init_type=INIT_WITH_ZEROES,
                     first_row_start_offset=0, first_row=None, first_column_init_type=INIT_WITH_ZEROES,
                     first_column_start_offset=0, stream_first_column=False, first_column=None,
-                    want_last_column=False, want_last_row=False, special_row_interval=0, track_best=True):
+                    want_last_column=False, want_last_row=False, special_row_interval=0, track_best=True,
+                    force_int32=False):
         sp = StreamParams()
         sp.recurrence_type = recurrence_type
         sp.first_row_init_type, sp.first_row_start_offset = first_row_init_type, first_row_start_offset
@@ -308,6 +309,7 @@ class MI355Aligner:
             a = _cells(first_column); keep.append(a); sp.first_column = a.ctypes.data
         sp.want_last_column, sp.want_last_row = int(want_last_column), int(want_last_row)
         sp.special_row_interval, sp.track_best = special_row_interval, int(track_best)
+        sp.force_int32 = int(force_int32)
         self._check(self._lib.mi355sw_stream_begin(self._h, C.byref(partition), C.byref(sp)), "streamBegin")
         self._stream_part = partition
 

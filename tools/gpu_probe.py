@@ -20,9 +20,10 @@ def check(m, n, related=True, rec=pkg.SMITH_WATERMAN, R=0, **kw):
     st = al.getStatistics()
     ref = oracle.stage1(s0, s1, recurrence=rec, block_h=st["strip_rows"], block_w=997, want_last_row=True, want_last_col=True,
                         first_row_type=kw.get("first_row_init_type", 0), first_col_type=kw.get("first_column_init_type", 0))
+    st["k"] = st["profile_kernel"]
     rb = ref["best"]; rb0 = (rb[0]-1, rb[1]-1, rb[2]) if rb[0] >= 0 else rb
     ok = (tuple(best) == tuple(rb0)) and np.array_equal(lr, ref["last_row"][1:]) and np.array_equal(lc, ref["last_col"][1:])
-    print("m=%d n=%d R=%d rec=%d best=%s ref=%s row_ok=%s col_ok=%s -> %s" % (m, n, st["strip_rows"]//64, rec, best, rb0,
+    print("k=%d m=%d n=%d R=%d rec=%d best=%s ref=%s row_ok=%s col_ok=%s -> %s" % (st["profile_kernel"], m, n, st["strip_rows"]//64, rec, best, rb0,
           np.array_equal(lr, ref["last_row"][1:]), np.array_equal(lc, ref["last_col"][1:]), "OK" if ok else "FAIL"), flush=True)
     al.close()
     return ok
@@ -48,9 +49,10 @@ def perf(m, n, R=0, waves=0):
 
 if __name__ == "__main__":
     allok = True
-    for (m, n) in [(100, 90), (513, 700), (5000, 4321), (2048, 64), (1, 1), (3000, 10000)]:
-        for R in (4, 8):
+    for (m, n) in [(100, 90), (513, 700), (5000, 4321), (2048, 64), (1, 1), (3000, 10000), (1025, 130), (257, 3)]:
+        for R in (4, 8, 16):
             allok &= check(m, n, R=R)
+            allok &= check(m, n, R=R, force_int32=True)
     allok &= check(4000, 3000, rec=pkg.NEEDLEMAN_WUNSCH, first_row_init_type=pkg.INIT_WITH_GAPS, first_column_init_type=pkg.INIT_WITH_GAPS, R=8)
     allok &= check(20000, 20000, related=False, R=8)
     print("ALL OK" if allok else "SOME FAILED", flush=True)

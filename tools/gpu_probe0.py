@@ -6,7 +6,7 @@ import numpy as np
 import __graft_entry__ as g
 pkg = g.load_package(); oracle = g.load_oracle()
 print("loaded", flush=True)
-al = pkg.MI355Aligner(device=0, rows_per_lane=8)
+al = pkg.MI355Aligner(device=0, rows_per_lane=4)
 print("created", al.getCapabilities()["smith_waterman"], flush=True)
 s0, s1 = pkg.seqgen.related_pair(100, 90, cfg=3)
 al.setSequences(s0, s1)
