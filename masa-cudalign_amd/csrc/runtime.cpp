@@ -65,7 +65,7 @@ struct mi355sw_handle {
     int n_match_codes = 0, pad_code = 0;
 
     // work buffers
-    DevBuf d_bus, d_first_col, d_special, d_last_row, d_progress, d_strip_best, d_ctrl, d_kargs;
+    DevBuf d_bus, d_first_col, d_special, d_last_row, d_progress, d_strip_best, d_ctrl, d_kargs, d_trace, d_ckpt;
     PinBuf p_first_col, p_last_col;  // streamed first column / last column (zero-copy)
     bool first_col_pinned = false;
     int* h_pinned = nullptr;        // [0] strips_done (kernel->host) [16] first_col_ready (host->kernel)
@@ -77,6 +77,12 @@ struct mi355sw_handle {
     mi355sw_stream_params sp{};
     int m = 0, n = 0, R = 8, SH = 512, strips = 0, waves = 0;
     bool use16 = false;             // packed 16-bit SW kernel selected for the active stream
+    bool two_phase = false;         // value-only tracking in the main pass + exact re-run of the winning strip
+    int ckpt_interval = 0, n_ckpt = 0;
+    long long ckpt_pitch = 0;
+    KernelArgs kargs{};             // arguments of the main pass (re-used by the exact pass)
+    mi355sw_score final_best{};
+    double exact_ms = 0;
     int special_interval_strips = 0, n_special = 0;
     long long special_pitch = 0;
     int fed_rows = 0;
@@ -193,7 +199,7 @@ void mi355sw_destroy(mi355sw_handle* h) {
     if (h->p_first_col.p) (void) hipHostFree(h->p_first_col.p);
     if (h->p_last_col.p) (void) hipHostFree(h->p_last_col.p);
     release(h->d_special); release(h->d_last_row); release(h->d_progress);
-    release(h->d_strip_best); release(h->d_ctrl); release(h->d_kargs);
+    release(h->d_strip_best); release(h->d_ctrl); release(h->d_kargs); release(h->d_ckpt); release(h->d_trace);
     if (h->h_pinned) (void) hipHostFree(h->h_pinned);
     if (h->ev0) (void) hipEventDestroy(h->ev0);
     if (h->ev1) (void) hipEventDestroy(h->ev1);
@@ -320,6 +326,23 @@ int mi355sw_stream_begin(mi355sw_handle* h, const mi355sw_partition* part, const
         h->n_special = (int) (((long long) m - 1) / ((long long) K * h->SH));   // rows K*SH*k < m
     }
     h->special_pitch = ((long long) n + 63) / 64 * 64;
+    h->use16 = (p->recurrence_type == MI355SW_SMITH_WATERMAN) && h->profile && !p->force_int32 &&
+               !(h->cfg.flags & MI355SW_F_FORCE_INT32);
+    // Two-phase best: the main pass keeps only each strip's best VALUE (no per-step position test, no
+    // rare path on the start-up critical path of every strip); the canonical cell is then recomputed
+    // for the first strip that holds the global maximum, from the nearest checkpoint row.
+    h->two_phase = h->use16 && p->track_best;
+    h->ckpt_interval = 0; h->n_ckpt = 0; h->ckpt_pitch = h->special_pitch;
+    if (h->two_phase) {
+        const int64_t budget = h->cfg.max_special_bytes > 0 ? h->cfg.max_special_bytes : (8LL << 30);
+        long long max_ck = budget / 2 / (long long) (sizeof(int2) * h->ckpt_pitch);
+        if (max_ck > 64) max_ck = 64;
+        if (max_ck < 1) max_ck = 1;
+        int K = (int) ((h->strips + max_ck - 1) / max_ck);
+        if (K < 1) K = 1;
+        h->ckpt_interval = K;
+        h->n_ckpt = (h->strips - 1) / K + 1;      // slots 0..(strips-1)/K
+    }
 
     int rc;
     if ((rc = ensure(h, h->d_bus, sizeof(int2) * ((size_t) n + 64)))) return rc;
@@ -327,6 +350,7 @@ int mi355sw_stream_begin(mi355sw_handle* h, const mi355sw_partition* part, const
     if ((rc = ensure(h, h->d_strip_best, sizeof(int4) * (size_t) h->strips))) return rc;
     if ((rc = ensure(h, h->d_ctrl, 256))) return rc;
     if ((rc = ensure(h, h->d_kargs, sizeof(KernelArgs)))) return rc;
+    if (h->two_phase && (rc = ensure(h, h->d_ckpt, sizeof(int2) * (size_t) h->ckpt_pitch * h->n_ckpt))) return rc;
     const bool need_first_col = (p->first_column_init_type != MI355SW_INIT_WITH_ZEROES);
     h->first_col_pinned = need_first_col && p->first_column_init_type == MI355SW_INIT_WITH_CUSTOM_DATA &&
                           p->stream_first_column;
@@ -387,6 +411,8 @@ int mi355sw_stream_begin(mi355sw_handle* h, const mi355sw_partition* part, const
             h->fed_rows = m;
         }
     }
+    if (h->two_phase)   // checkpoint slot 0 = the first row
+        HIPCHK(h, hipMemcpyAsync(h->d_ckpt.p, h->d_bus.p, sizeof(int2) * (size_t) n, hipMemcpyDeviceToDevice, h->stream));
     // synchronisation words
     HIPCHK(h, hipMemsetAsync(h->d_progress.p, 0, sizeof(int) * ((size_t) h->strips + 1), h->stream));
     HIPCHK(h, launch_fill_int((int*) h->d_progress.p, 1, n, h->stream));   // virtual strip above: all columns ready
@@ -410,6 +436,9 @@ int mi355sw_stream_begin(mi355sw_handle* h, const mi355sw_partition* part, const
     a.special_pitch = h->special_pitch;
     a.special_interval_strips = h->n_special > 0 ? h->special_interval_strips : 0;
     a.last_row = p->want_last_row ? (int2*) h->d_last_row.p : nullptr;
+    a.ckpt_rows = h->two_phase ? (int2*) h->d_ckpt.p : nullptr;
+    a.ckpt_pitch = h->ckpt_pitch;
+    a.ckpt_interval_strips = h->ckpt_interval;
     a.progress = (int*) h->d_progress.p;
     int* ctrl = (int*) h->d_ctrl.p;
     a.ticket = ctrl + 0;
@@ -420,6 +449,12 @@ int mi355sw_stream_begin(mi355sw_handle* h, const mi355sw_partition* part, const
     a.first_col_ready = (need_first_col && p->stream_first_column) ? h->h_pinned + 16 : nullptr;
     a.strip_best = (int4*) h->d_strip_best.p;
     a.dbg = getenv("MI355SW_DEBUG") ? ctrl + 56 : nullptr;
+    a.trace = nullptr;
+    if (getenv("MI355SW_TRACE")) {
+        if ((rc = ensure(h, h->d_trace, sizeof(long long) * 4 * (size_t) h->strips))) return rc;
+        HIPCHK(h, hipMemsetAsync(h->d_trace.p, 0, sizeof(long long) * 4 * (size_t) h->strips, h->stream));
+        a.trace = (long long*) h->d_trace.p;
+    }
 
     h->stats = mi355sw_stats{};
     h->stats.cells = (int64_t) m * n;
@@ -433,11 +468,12 @@ int mi355sw_stream_begin(mi355sw_handle* h, const mi355sw_partition* part, const
     h->prog_total = h->strips;
 
     HIPCHK(h, hipEventRecord(h->ev0, h->stream));
-    h->use16 = (p->recurrence_type == MI355SW_SMITH_WATERMAN) && h->profile && !p->force_int32 &&
-               !(h->cfg.flags & MI355SW_F_FORCE_INT32);
+    h->kargs = a;
+    h->exact_ms = 0;
     if (h->use16) {
         h->stats.profile_kernel = 2;
-        HIPCHK(h, launch_strip_kernel_pk16(a, (KernelArgs*) h->d_kargs.p, h->R / 2, waves, h->stream, p->track_best != 0));
+        HIPCHK(h, launch_strip_kernel_pk16(a, (KernelArgs*) h->d_kargs.p, h->R / 2, waves, h->stream,
+                                           p->track_best != 0 && !h->two_phase));
     } else {
         HIPCHK(h, launch_strip_kernel(a, (KernelArgs*) h->d_kargs.p, h->R, waves, h->stream, p->recurrence_type == MI355SW_SMITH_WATERMAN,
                                       h->profile, p->track_best != 0));
@@ -554,6 +590,52 @@ int mi355sw_stream_abort(mi355sw_handle* h) {
     return MI355SW_OK;
 }
 
+// Exact-position pass of the two-phase scheme: re-run strips [ck*K, s_star] with exact canonical tracking,
+// starting from checkpoint row ck (the bus row above strip ck*K); returns the canonical cell of s_star.
+static int run_exact_pass(mi355sw_handle* h, int s_star, int want_score, mi355sw_score* out) {
+    const int K = h->ckpt_interval;
+    const int ck = s_star / K;
+    const int start = ck * K;
+    const int count = s_star - start + 1;
+    HIPCHK(h, hipMemcpyAsync(h->d_bus.p, (int2*) h->d_ckpt.p + (size_t) ck * h->ckpt_pitch, sizeof(int2) * (size_t) h->n,
+                             hipMemcpyDeviceToDevice, h->stream));
+    HIPCHK(h, hipMemsetAsync(h->d_progress.p, 0, sizeof(int) * ((size_t) count + 1), h->stream));
+    HIPCHK(h, launch_fill_int((int*) h->d_progress.p, 1, h->n, h->stream));
+    HIPCHK(h, hipMemsetAsync(h->d_ctrl.p, 0, 256, h->stream));
+    HIPCHK(h, hipMemsetAsync(h->d_strip_best.p, 0, sizeof(int4) * (size_t) count, h->stream));
+    h->h_pinned[0] = 0;
+    KernelArgs b = h->kargs;
+    b.num_strips = count;
+    b.strip_row0 = start * h->SH;
+    b.strip_index0 = start;
+    b.special_rows = nullptr; b.special_interval_strips = 0;
+    b.last_col = nullptr; b.last_row = nullptr; b.ckpt_rows = nullptr; b.ckpt_interval_strips = 0;
+    b.first_col_ready = nullptr;        // every row of a streamed first column has arrived by now
+    b.trace = nullptr;
+    int waves = std::min(count, h->waves);
+    hipEvent_t e0, e1;
+    HIPCHK(h, hipEventCreate(&e0));
+    HIPCHK(h, hipEventCreate(&e1));
+    HIPCHK(h, hipEventRecord(e0, h->stream));
+    HIPCHK(h, launch_strip_kernel_pk16(b, (KernelArgs*) h->d_kargs.p, h->R / 2, waves, h->stream, true));
+    HIPCHK(h, hipEventRecord(e1, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    float ms = 0.f;
+    HIPCHK(h, hipEventElapsedTime(&ms, e0, e1));
+    (void) hipEventDestroy(e0); (void) hipEventDestroy(e1);
+    h->exact_ms = ms;
+    int ctrl[64];
+    HIPCHK(h, hipMemcpy(ctrl, h->d_ctrl.p, sizeof(ctrl), hipMemcpyDeviceToHost));
+    if (ctrl[32] == 16) FAIL(h, MI355SW_EOVERFLOW16, "packed 16-bit kernel left its exact range in the exact pass");
+    if (ctrl[32] != 0) FAIL(h, MI355SW_ETIMEOUT, "in-kernel wait timed out in the exact pass (code %d)", ctrl[32]);
+    int4 r;
+    HIPCHK(h, hipMemcpy(&r, (int4*) h->d_strip_best.p + (count - 1), sizeof(int4), hipMemcpyDeviceToHost));
+    if (r.w != 1 || r.z < 0 || r.x != want_score)
+        FAIL(h, MI355SW_ESTATE, "exact pass disagrees with the main pass (strip %d: %d vs %d)", s_star, r.x, want_score);
+    out->score = r.x; out->i = r.y; out->j = r.z;
+    return MI355SW_OK;
+}
+
 int mi355sw_stream_end(mi355sw_handle* h, mi355sw_score* best, int32_t* n_special_rows) {
     if (!h || !h->active) return MI355SW_ESTATE;
     hipError_t e = hipStreamSynchronize(h->stream);
@@ -569,12 +651,32 @@ int mi355sw_stream_end(mi355sw_handle* h, mi355sw_score* best, int32_t* n_specia
     const bool aborted = ctrl[16] != 0;
     if (ctrl[32] == 16) FAIL(h, MI355SW_EOVERFLOW16, "packed 16-bit kernel left its exact range; rerun with force_int32");
     if (ctrl[32] != 0) FAIL(h, MI355SW_ETIMEOUT, "in-kernel wait timed out (code %d)", ctrl[32]);
+    if (getenv("MI355SW_TRACE") && h->d_trace.p) {
+        std::vector<long long> tr((size_t) h->strips * 4);
+        HIPCHK(h, hipMemcpy(tr.data(), h->d_trace.p, tr.size() * sizeof(long long), hipMemcpyDeviceToHost));
+        FILE* f = fopen(getenv("MI355SW_TRACE"), "wb");
+        if (f) { fwrite(tr.data(), sizeof(long long), tr.size(), f); fclose(f); }
+    }
     h->strip_best_host.resize((size_t) h->strips);
     HIPCHK(h, hipMemcpy(h->strip_best_host.data(), h->d_strip_best.p, sizeof(int4) * (size_t) h->strips,
                         hipMemcpyDeviceToHost));
     mi355sw_score b;
     b.i = -1; b.j = -1; b.score = -MI355SW_INF;
-    if (h->sp.track_best) {
+    if (h->sp.track_best && h->two_phase && !aborted) {
+        // main pass recorded values only: first strip holding the maximum, then its exact canonical cell
+        int S = -MI355SW_INF, s_star = -1;
+        for (int s = 0; s < h->strips; s++) {
+            const int4 r = h->strip_best_host[(size_t) s];
+            if (r.w != 0 && r.x > S) { S = r.x; s_star = s; }
+        }
+        if (s_star >= 0) {
+            int rc2 = run_exact_pass(h, s_star, S, &b);
+            if (rc2) return rc2;
+            b.i += h->part.i0; b.j += h->part.j0;
+        }
+        h->stats.kernel_ms += h->exact_ms;
+        h->stats.kernel_launches = 2;
+    } else if (h->sp.track_best) {
         // canonical order of BestScoreList (M/common/BestScoreList.hpp:30-38): score desc, i asc, j asc
         for (int s = 0; s < h->strips; s++) {
             const int4 r = h->strip_best_host[(size_t) s];
@@ -585,6 +687,7 @@ int mi355sw_stream_end(mi355sw_handle* h, mi355sw_score* best, int32_t* n_specia
         }
         if (b.j >= 0) { b.i += h->part.i0; b.j += h->part.j0; }
     }
+    h->final_best = b;
     if (best) *best = b;
     if (n_special_rows) *n_special_rows = h->n_special;
     const int done_strips = aborted ? ctrl[48] : h->strips;
@@ -598,6 +701,11 @@ int mi355sw_stream_end(mi355sw_handle* h, mi355sw_score* best, int32_t* n_specia
 
 int mi355sw_stream_strip_scores(mi355sw_handle* h, mi355sw_score* out, int32_t max_count) {
     if (!h || !out) return MI355SW_EINVAL;
+    if (h->two_phase) {   // only the global best has an exact position in the two-phase scheme
+        if (max_count < 1 || h->final_best.j < 0) return 0;
+        out[0] = h->final_best;
+        return 1;
+    }
     int cnt = 0;
     for (size_t s = 0; s < h->strip_best_host.size() && cnt < max_count; s++) {
         const int4 r = h->strip_best_host[s];

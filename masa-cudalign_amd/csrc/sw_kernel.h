@@ -30,6 +30,9 @@ struct KernelArgs {
     long long special_pitch;
     int special_interval_strips; // every K-th strip end is flushed (0 = none)
     int2* last_row;              // n cells (H,F) of DP row m, or nullptr
+    int2* ckpt_rows;             // checkpoint rows for the exact-position pass: slot k = bus row below strip k*K-1
+    long long ckpt_pitch;        //   (slot 0 = the first row, written by the host), or nullptr
+    int ckpt_interval_strips;    // K
     // synchronisation / results
     int* progress;               // num_strips+1 ints; progress[0] = n (virtual strip above)
     int* ticket;                 // next strip to claim
@@ -40,6 +43,7 @@ struct KernelArgs {
     int* strips_done_host;       // pinned host mirror (system scope)
     int4* strip_best;            // per strip {score, i, j, valid}
     int* dbg;                    // optional debug words (nullptr in production)
+    long long* trace;            // optional per-strip timing {start,end,poll spins,first chunk} (nullptr in production)
 };
 
 // The argument block lives in device memory and is read through the constant address space with a

@@ -141,7 +141,8 @@ __device__ __forceinline__ void wave_step16(Lane16<R>& st, WaveLds16* lds, const
         newT[r] = T;
         upT = T;
         upF = Fv;
-        ms = pmax(ms, T);
+        if (MASKED) ms = pmax(ms, as_s2((as_i(T) & vmask) | (0x80008000 & ~vmask)));
+        else ms = pmax(ms, T);
         if (EMIT_ANY) {
             t_emit = (r == emit_row) ? T : t_emit;
             f_emit = (r == emit_row) ? Fv : f_emit;
@@ -220,6 +221,12 @@ __device__ __attribute__((noinline)) void process_strip16(const KernelArgs* ap, 
             special = a->special_rows + (long long) (sg / a->special_interval_strips - 1) * a->special_pitch;
     }
     int2* lastrow = (last_strip && a->last_row != nullptr) ? a->last_row : nullptr;
+    int2* ckpt = nullptr;
+    if (a->ckpt_rows != nullptr && a->ckpt_interval_strips > 0) {
+        const int sg = a->strip_index0 + s + 1;
+        if (sg % a->ckpt_interval_strips == 0 && !last_strip)
+            ckpt = a->ckpt_rows + (long long) (sg / a->ckpt_interval_strips) * a->ckpt_pitch;
+    }
 
     bool overflow = false;
     // ---- first column ----
@@ -269,12 +276,15 @@ __device__ __attribute__((noinline)) void process_strip16(const KernelArgs* ap, 
     st.tbot = splat(-32768);
     st.fbot = splat(-32768);
     st.best_t = NEG_INF; st.best_r = 2 * R; st.best_j = -1;
+    s2 lane_max = splat(-32768);
 
     // seq1 window starts empty
     lds->c1w[lane] = 0; lds->c1w[64 + lane] = 0; lds->c1w[128 + lane] = 0;
     if (lane < 8) lds->c1w[192 + lane] = 0;
 
     DBG16(1, 1);
+    long long tr_start = 0, tr_first = 0; int tr_spins = 0;
+    if (a->trace != nullptr) tr_start = __builtin_amdgcn_s_memrealtime();
     for (int c = 0; c < nchunks; c++) {
         const int col0 = c * CHUNK;
         DBG16(2, c); DBG16(3, 10);
@@ -288,6 +298,7 @@ __device__ __attribute__((noinline)) void process_strip16(const KernelArgs* ap, 
                     __builtin_amdgcn_s_sleep(2);
                     spins++;
                 }
+                tr_spins += spins;
                 if (spins >= (1 << 24) && lane == 0) atomicExch(a->error_flag, 1);
             }
             const int col = col0 + lane;
@@ -332,7 +343,10 @@ __device__ __attribute__((noinline)) void process_strip16(const KernelArgs* ap, 
             for (int u = 0; u < CHUNK; u++)
                 wave_step16<R, false, TRACK, false>(st, lds, u, lane, jl, n, nvalid_lo, nvalid_hi, 63, R - 1, Z, bias, feed, c1, cmax);
         }
+        if (a->trace != nullptr && c == nchunks / 2) tr_first = __builtin_amdgcn_s_memrealtime();
+        if (a->trace != nullptr && c == nchunks / 2 + 1000) tr_start = __builtin_amdgcn_s_memrealtime();
         DBG16(3, 30);
+        lane_max = pmax(lane_max, cmax);
         // 16-bit range guard (wave-uniform)
         {
             const int cm = as_i(cmax);
@@ -353,6 +367,7 @@ __device__ __attribute__((noinline)) void process_strip16(const KernelArgs* ap, 
                 st_agent2_16(&a->bus[col], hf);
                 if (special != nullptr) special[col] = hf;
                 if (lastrow != nullptr) lastrow[col] = hf;
+                if (ckpt != nullptr) ckpt[col] = hf;
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             int done = col0 - emit_v + CHUNK;
@@ -364,6 +379,10 @@ __device__ __attribute__((noinline)) void process_strip16(const KernelArgs* ap, 
 
     if (__any(overflow)) {
         if (lane == 0) { atomicExch(a->error_flag, 16); st_agent16(a->abort_flag, 1); }
+    }
+    if (a->trace != nullptr && lane == 0) {
+        a->trace[4 * s + 0] = tr_start; a->trace[4 * s + 1] = __builtin_amdgcn_s_memrealtime();
+        a->trace[4 * s + 2] = tr_spins; a->trace[4 * s + 3] = tr_first;
     }
     DBG16(3, 40);
     // ---- strip epilogue ----
@@ -397,6 +416,23 @@ __device__ __attribute__((noinline)) void process_strip16(const KernelArgs* ap, 
             int4 rec;
             rec.x = (bj >= 0) ? bt + T_OFF : NEG_INF;
             rec.y = bi; rec.z = bj; rec.w = 1;
+            a->strip_best[s] = rec;
+        }
+        __builtin_amdgcn_wave_barrier();
+    } else {
+        // value-only record: the strip's best score; the exact canonical cell of the winning strip is
+        // recomputed afterwards from the nearest checkpoint row by the exact-tracking kernel (runtime.cpp)
+        const int lm = as_i(lane_max);
+        lds->red[lane] = max(lo16(lm), hi16(lm));
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (lane == 0) {
+            int bt = -32768;
+            for (int k = 0; k < 64; k++) bt = max(bt, lds->red[k]);
+            int4 rec;
+            rec.x = (bt > -32768) ? bt + T_OFF + bias : NEG_INF;
+            rec.y = -1; rec.z = -1; rec.w = 2;
             a->strip_best[s] = rec;
         }
         __builtin_amdgcn_wave_barrier();

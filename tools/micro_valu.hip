@@ -34,6 +34,22 @@ __global__ void __launch_bounds__(64) k(int* out, int iters, long long* cycles) 
                 b = __builtin_amdgcn_update_dpp(b, c, 0x111, 0xf, 0xf, false) + 1;
                 c = __builtin_amdgcn_update_dpp(c, d, 0x111, 0xf, 0xf, false) + 1;
                 d = __builtin_amdgcn_update_dpp(d, a, 0x111, 0xf, 0xf, false) + 1;
+            } else if (MODE == 6) {   // SERIAL dependent chain, packed i16 (one chain)
+                typedef short s2 __attribute__((ext_vector_type(2)));
+                s2 x = __builtin_bit_cast(s2, a), y = __builtin_bit_cast(s2, b);
+                s2 m2 = {-2, -2};
+                x = __builtin_elementwise_max(x + m2, y); x = __builtin_elementwise_max(x + m2, y);
+                x = __builtin_elementwise_max(x + m2, y); x = __builtin_elementwise_max(x + m2, y);
+                a = __builtin_bit_cast(int, x);
+            } else if (MODE == 7) {   // SERIAL dependent chain, int32
+                a = max(a + -2, b); a = max(a + -2, b); a = max(a + -2, b); a = max(a + -2, b);
+            } else if (MODE == 8) {   // two interleaved dependent chains, packed
+                typedef short s2 __attribute__((ext_vector_type(2)));
+                s2 x = __builtin_bit_cast(s2, a), y = __builtin_bit_cast(s2, b), z = __builtin_bit_cast(s2, c);
+                s2 m2 = {-2, -2};
+                x = __builtin_elementwise_max(x + m2, y); z = __builtin_elementwise_max(z + m2, y);
+                x = __builtin_elementwise_max(x + m2, y); z = __builtin_elementwise_max(z + m2, y);
+                a = __builtin_bit_cast(int, x); c = __builtin_bit_cast(int, z);
             } else if (MODE == 5) {   // packed i16 max/add
                 typedef short s2 __attribute__((ext_vector_type(2)));
                 s2 x = __builtin_bit_cast(s2, a), y = __builtin_bit_cast(s2, b), z = __builtin_bit_cast(s2, c), w = __builtin_bit_cast(s2, d);
@@ -78,5 +94,8 @@ int main() {
     run<3>("dpp_wshr+add", 8);
     run<4>("dpp_rshr+add", 8);
     run<5>("pk_i16", 8);
+    run<6>("pk_serial", 8);
+    run<7>("i32_serial", 8);
+    run<8>("pk_2chains", 8);
     return 0;
 }
