@@ -25,8 +25,12 @@ sys.path.insert(0, ROOT)
 import __graft_entry__ as graft  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0                 # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-# int32 VALU issue measured on this chip (tools/micro_valu.hip): 1 wave64 op / 4 cycles / SIMD
-VALU_PEAK_LANE_OPS = 256 * 4 * 16 * 2.4e9
+# VALU issue measured on this chip (tools/micro_valu.hip): one wave64 instruction (int32 or packed 2x16)
+# per 4 cycles per SIMD, i.e. 0.59 wave-instructions/ns/SIMD at the 2.38 GHz the chip holds under this load
+VALU_PEAK_WAVE_INSTR = 256 * 4 * 0.59e9
+# VALU instructions per wave-step (SQ_INSTS_VALU / steps; one step = strip_rows cells)
+VALU_PER_STEP = {("int32", 256): 47.0, ("int32", 512): 86.3, ("int32", 1024): 165.0,
+                 ("pk16", 256): 35.0, ("pk16", 512): 59.0, ("pk16", 1024): 107.0}
 
 
 def cpu_baseline(pkg, seconds_budget=20.0):
@@ -167,20 +171,21 @@ def main():
             "metric": "GCUPS (DP cells/sec) Stage-1", "value": gcups, "unit": "GCUPS",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "i16x2 (packed, exact; int32 fallback)" if st["profile_kernel"] == 2 else "int32",
+            "data": "synthetic",
             "config": {"workload": ("C2: %dx%d unrelated random ACGT, local SW, score-only" % (m, n)) if world == 1 else
                        ("weak scaling of C2: (%d*%d)x%d, %d column bands of %d columns, boundary column over RCCL p2p"
                         % (args.size, world, n, world, n // world)),
                        "m": m, "n": n, "bands": world, "strip_rows": st["strip_rows"], "waves_per_gpu": st["waves"],
-                       "kernel": "profile" if st["profile_kernel"] else "generic", "comm": comm if world > 1 else "none"},
+                       "kernel": {2: "pk16", 1: "int32-profile", 0: "int32-generic"}[st["profile_kernel"]],
+                       "comm": comm if world > 1 else "none"},
             "best": {"i": best[0] + 1, "j": best[1] + 1, "score": best[2]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "sw_strip_kernel", "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_bytes,
-                         "note": "scan kernel: 17 B per column per %d-row strip; the binding unit is int32 VALU issue" % st["strip_rows"]},
-            "valu_roofline": {"ops_per_cell": 10.8, "achieved_lane_ops": band_cells * 10.8 / (k_ms * 1e-3),
-                              "peak_lane_ops": VALU_PEAK_LANE_OPS,
-                              "frac": band_cells * 10.8 / (k_ms * 1e-3) / VALU_PEAK_LANE_OPS},
+                         "kernel": "sw_strip_kernel_pk16" if st["profile_kernel"] == 2 else "sw_strip_kernel",
+                         "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_bytes,
+                         "note": "scan kernel: 17 B per column per %d-row strip; the binding unit is VALU issue" % st["strip_rows"]},
+            "valu_roofline": _valu(st, band_cells, k_ms),
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pkg)
@@ -189,6 +194,14 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def _valu(st, band_cells, k_ms):
+    kind = "pk16" if st["profile_kernel"] == 2 else "int32"
+    per_step = VALU_PER_STEP.get((kind, st["strip_rows"]), 86.3)
+    achieved = band_cells / st["strip_rows"] * per_step / (k_ms * 1e-3)
+    return {"valu_instr_per_step": per_step, "cells_per_step": st["strip_rows"], "achieved_wave_instr_per_s": achieved,
+            "peak_wave_instr_per_s": VALU_PEAK_WAVE_INSTR, "frac": achieved / VALU_PEAK_WAVE_INSTR}
 
 
 def _reduce_cpu(dist, best, world, device):

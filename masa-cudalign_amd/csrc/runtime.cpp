@@ -331,7 +331,10 @@ int mi355sw_stream_begin(mi355sw_handle* h, const mi355sw_partition* part, const
     // Two-phase best: the main pass keeps only each strip's best VALUE (no per-step position test, no
     // rare path on the start-up critical path of every strip); the canonical cell is then recomputed
     // for the first strip that holds the global maximum, from the nearest checkpoint row.
-    h->two_phase = h->use16 && p->track_best;
+    // The exact pass costs one strip sweep (n steps of a short pipeline); it pays off once the main pass
+    // is hundreds of sweeps long.  Smaller partitions keep exact tracking in the main pass, seeded with the
+    // running global best so that it stays off the start-up path.
+    h->two_phase = h->use16 && p->track_best && (m >= (32 << 20) || getenv("MI355SW_TWO_PHASE"));
     h->ckpt_interval = 0; h->n_ckpt = 0; h->ckpt_pitch = h->special_pitch;
     if (h->two_phase) {
         const int64_t budget = h->cfg.max_special_bytes > 0 ? h->cfg.max_special_bytes : (8LL << 30);
@@ -417,6 +420,7 @@ int mi355sw_stream_begin(mi355sw_handle* h, const mi355sw_partition* part, const
     HIPCHK(h, hipMemsetAsync(h->d_progress.p, 0, sizeof(int) * ((size_t) h->strips + 1), h->stream));
     HIPCHK(h, launch_fill_int((int*) h->d_progress.p, 1, n, h->stream));   // virtual strip above: all columns ready
     HIPCHK(h, hipMemsetAsync(h->d_ctrl.p, 0, 256, h->stream));
+    HIPCHK(h, launch_fill_int((int*) h->d_ctrl.p + 52, 1, -MI355SW_INF, h->stream));   // running global best
     HIPCHK(h, hipMemsetAsync(h->d_strip_best.p, 0, sizeof(int4) * (size_t) h->strips, h->stream));
     h->h_pinned[0] = 0;
 
@@ -447,6 +451,7 @@ int mi355sw_stream_begin(mi355sw_handle* h, const mi355sw_partition* part, const
     a.strips_done_dev = ctrl + 48;
     a.strips_done_host = getenv("MI355SW_NOHOST") ? nullptr : h->h_pinned + 0;
     a.first_col_ready = (need_first_col && p->stream_first_column) ? h->h_pinned + 16 : nullptr;
+    a.gbest = ctrl + 52;
     a.strip_best = (int4*) h->d_strip_best.p;
     a.dbg = getenv("MI355SW_DEBUG") ? ctrl + 56 : nullptr;
     a.trace = nullptr;
@@ -602,6 +607,7 @@ static int run_exact_pass(mi355sw_handle* h, int s_star, int want_score, mi355sw
     HIPCHK(h, hipMemsetAsync(h->d_progress.p, 0, sizeof(int) * ((size_t) count + 1), h->stream));
     HIPCHK(h, launch_fill_int((int*) h->d_progress.p, 1, h->n, h->stream));
     HIPCHK(h, hipMemsetAsync(h->d_ctrl.p, 0, 256, h->stream));
+    HIPCHK(h, launch_fill_int((int*) h->d_ctrl.p + 52, 1, -MI355SW_INF, h->stream));
     HIPCHK(h, hipMemsetAsync(h->d_strip_best.p, 0, sizeof(int4) * (size_t) count, h->stream));
     h->h_pinned[0] = 0;
     KernelArgs b = h->kargs;

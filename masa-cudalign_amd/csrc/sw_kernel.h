@@ -41,6 +41,7 @@ struct KernelArgs {
     const int* first_col_ready;  // pinned host counter: rows of first_col that are valid, or nullptr (all)
     int* strips_done_dev;        // device counter, ordered: value s means strips [0,s) complete
     int* strips_done_host;       // pinned host mirror (system scope)
+    int* gbest;                  // running global best (T domain): lower bound that seeds every lane's threshold
     int4* strip_best;            // per strip {score, i, j, valid}
     int* dbg;                    // optional debug words (nullptr in production)
     long long* trace;            // optional per-strip timing {start,end,poll spins,first chunk} (nullptr in production)

@@ -32,6 +32,7 @@ namespace mi355sw {
 
 #define NEG_INF (-999999999)
 #define T_OFF 3            // T = H - 3
+#define PRIO_CHUNKS 4       // chunks of every strip that run at raised wave priority
 #define GUARD16 30000      // chunk maximum above this => overflow report (wrap needs 32767)
 
 typedef unsigned int u32;
@@ -186,6 +187,18 @@ __device__ __forceinline__ void wave_step16(Lane16<R>& st, WaveLds16* lds, const
     }
 }
 
+// 64 systolic steps of one chunk (reads the staged inputs from LDS, leaves the emit row in out_tf)
+template <int R, bool MASKED, bool TRACKSTEP, bool EMIT_ANY>
+__device__ __forceinline__ void run_chunk16(Lane16<R>& st, WaveLds16* lds, const int lane, const int jl, const int n,
+                                            const int nvalid_lo, const int nvalid_hi, const int emit_lane,
+                                            const int emit_row, const s2 Z, const int bias, s2& cmax) {
+    int2 feed = lds->in_tf[0];
+    int c1 = lds->c1w[WIN - 2 * lane];
+#pragma unroll 2
+    for (int u = 0; u < CHUNK; u++)
+        wave_step16<R, MASKED, TRACKSTEP, EMIT_ANY>(st, lds, u, lane, jl, n, nvalid_lo, nvalid_hi, emit_lane, emit_row, Z, bias, feed, c1, cmax);
+}
+
 template <int R, bool TRACK>
 __device__ __attribute__((noinline)) void process_strip16(const KernelArgs* ap, const int s_in, WaveLds16* lds, const int lane) {
     const UniformArgs a = uniform_args(ap);
@@ -277,6 +290,7 @@ __device__ __attribute__((noinline)) void process_strip16(const KernelArgs* ap, 
     st.fbot = splat(-32768);
     st.best_t = NEG_INF; st.best_r = 2 * R; st.best_j = -1;
     s2 lane_max = splat(-32768);
+    int gseen = NEG_INF;
 
     // seq1 window starts empty
     lds->c1w[lane] = 0; lds->c1w[64 + lane] = 0; lds->c1w[128 + lane] = 0;
@@ -285,9 +299,20 @@ __device__ __attribute__((noinline)) void process_strip16(const KernelArgs* ap, 
     DBG16(1, 1);
     long long tr_start = 0, tr_first = 0; int tr_spins = 0;
     if (a->trace != nullptr) tr_start = __builtin_amdgcn_s_memrealtime();
+    // The first chunks of a strip are the critical path of the pipeline's start-up: the next strip cannot
+    // begin before they are published.  Run them at raised priority so that they proceed at single-wave
+    // speed instead of a quarter of the SIMD (measured: hop 250 us -> ~50 us with 4 waves per SIMD).
+    __builtin_amdgcn_s_setprio(3);
     for (int c = 0; c < nchunks; c++) {
         const int col0 = c * CHUNK;
+        // graded: the younger the strip, the closer it is to the start-up front of the pipeline
+        if (c == 8) __builtin_amdgcn_s_setprio(2);
+        else if (c == 48) __builtin_amdgcn_s_setprio(1);
+        else if (c == 256) __builtin_amdgcn_s_setprio(0);
         DBG16(2, c); DBG16(3, 10);
+        const bool trc = (a->trace != nullptr) && (c == 1000 || c == 1);
+        long long q0 = 0, q1 = 0, q2 = 0, q3 = 0, q4 = 0;
+        if (trc) q0 = __builtin_amdgcn_s_memrealtime();
         // (1) stage the input chunk
         {
             int need = col0 + CHUNK;
@@ -299,8 +324,18 @@ __device__ __attribute__((noinline)) void process_strip16(const KernelArgs* ap, 
                     spins++;
                 }
                 tr_spins += spins;
+
                 if (spins >= (1 << 24) && lane == 0) atomicExch(a->error_flag, 1);
             }
+            if (TRACK) {
+                // Seed: a cell below the best score already found anywhere can never be the answer, so every
+                // lane starts from the global running best (ties are still taken: the test below is >=).
+                // Without it each strip spends its first chunks in the exact path and the start-up delay of
+                // every hop of the strip pipeline triples.
+                gseen = poll_agent16(a->gbest);
+                if (gseen > st.best_t) { st.best_t = gseen; st.best_r = 2 * R; st.best_j = -1; }
+            }
+            if (trc) q1 = __builtin_amdgcn_s_memrealtime();
             const int col = col0 + lane;
             int2 hf = make_int2(0, NEG_INF);
             int code = 255, codep = 255;
@@ -323,34 +358,49 @@ __device__ __attribute__((noinline)) void process_strip16(const KernelArgs* ap, 
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
+        if (trc) q2 = __builtin_amdgcn_s_memrealtime();
         DBG16(3, 20);
         // (2) 64 systolic steps
         const int jl = col0 - 2 * lane;
         const bool masked = (col0 - 127 < 0) || (col0 + CHUNK - 1 >= n);
-        int2 feed = lds->in_tf[0];
-        int c1 = lds->c1w[WIN - 2 * lane];
         s2 cmax = splat(-32768);
-        if (ragged) {
-#pragma unroll 2
-            for (int u = 0; u < CHUNK; u++)
-                wave_step16<R, true, TRACK, true>(st, lds, u, lane, jl, n, nvalid_lo, nvalid_hi, emit_lane, emit_row, Z, bias, feed, c1, cmax);
-        } else if (masked) {
-#pragma unroll 2
-            for (int u = 0; u < CHUNK; u++)
-                wave_step16<R, true, TRACK, false>(st, lds, u, lane, jl, n, nvalid_lo, nvalid_hi, 63, R - 1, Z, bias, feed, c1, cmax);
-        } else {
-#pragma unroll 2
-            for (int u = 0; u < CHUNK; u++)
-                wave_step16<R, false, TRACK, false>(st, lds, u, lane, jl, n, nvalid_lo, nvalid_hi, 63, R - 1, Z, bias, feed, c1, cmax);
+        // Fast pass: no position bookkeeping at all.  Only if some lane's chunk maximum reaches its
+        // (globally seeded) threshold is the chunk replayed from a register snapshot with the exact
+        // per-step bookkeeping -- a rare event once the running best is above the background level.
+        Lane16<R> snap;
+        if (TRACK) {
+#pragma unroll
+            for (int r = 0; r < R; r++) { snap.TL[r] = st.TL[r]; snap.E[r] = st.E[r]; }
+            snap.tup_prev = st.tup_prev; snap.tbot = st.tbot; snap.fbot = st.fbot;
         }
-        if (a->trace != nullptr && c == nchunks / 2) tr_first = __builtin_amdgcn_s_memrealtime();
-        if (a->trace != nullptr && c == nchunks / 2 + 1000) tr_start = __builtin_amdgcn_s_memrealtime();
+        if (ragged) run_chunk16<R, true, false, true>(st, lds, lane, jl, n, nvalid_lo, nvalid_hi, emit_lane, emit_row, Z, bias, cmax);
+        else if (masked) run_chunk16<R, true, false, false>(st, lds, lane, jl, n, nvalid_lo, nvalid_hi, 63, R - 1, Z, bias, cmax);
+        else run_chunk16<R, false, false, false>(st, lds, lane, jl, n, nvalid_lo, nvalid_hi, 63, R - 1, Z, bias, cmax);
+        if (TRACK) {
+            const int cm0 = as_i(cmax);
+            if (__any(max(lo16(cm0), hi16(cm0)) + bias >= st.best_t)) {
+#pragma unroll
+                for (int r = 0; r < R; r++) { st.TL[r] = snap.TL[r]; st.E[r] = snap.E[r]; }
+                st.tup_prev = snap.tup_prev; st.tbot = snap.tbot; st.fbot = snap.fbot;
+                s2 cmax2 = splat(-32768);
+                if (ragged) run_chunk16<R, true, true, true>(st, lds, lane, jl, n, nvalid_lo, nvalid_hi, emit_lane, emit_row, Z, bias, cmax2);
+                else run_chunk16<R, true, true, false>(st, lds, lane, jl, n, nvalid_lo, nvalid_hi, 63, R - 1, Z, bias, cmax2);
+            }
+        }
+        if (trc) q3 = __builtin_amdgcn_s_memrealtime();
         DBG16(3, 30);
         lane_max = pmax(lane_max, cmax);
-        // 16-bit range guard (wave-uniform)
+        // 16-bit range guard (wave-uniform) and publication of a new global best
         {
             const int cm = as_i(cmax);
-            if (max(lo16(cm), hi16(cm)) > GUARD16) overflow = true;
+            const int cmv = max(lo16(cm), hi16(cm));
+            if (cmv > GUARD16) overflow = true;
+            if (TRACK && __any(cmv + bias > gseen)) {
+                int w = cmv + bias;
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1) w = max(w, __shfl_xor(w, d));
+                if (lane == 0) atomicMax(a->gbest, w);
+            }
         }
         // (3) output chunk: columns col0-emit_v .. col0-emit_v+63
         {
@@ -375,14 +425,20 @@ __device__ __attribute__((noinline)) void process_strip16(const KernelArgs* ap, 
             if (done < 0) done = 0;
             if (lane == 0) st_agent16(prog_out, done);
         }
+        if (trc && lane == 0) {
+            q4 = __builtin_amdgcn_s_memrealtime();
+            long long* tr = a->trace + 4 * s;
+            const long long v = ((q1 - q0) & 0xffff) | (((q2 - q1) & 0xffff) << 16) | (((q3 - q2) & 0xffff) << 32) | (((q4 - q3) & 0xffff) << 48);
+            if (c == 1) tr[2] = v; else tr[3] = v;
+        }
     }
 
+    __builtin_amdgcn_s_setprio(0);
     if (__any(overflow)) {
         if (lane == 0) { atomicExch(a->error_flag, 16); st_agent16(a->abort_flag, 1); }
     }
     if (a->trace != nullptr && lane == 0) {
         a->trace[4 * s + 0] = tr_start; a->trace[4 * s + 1] = __builtin_amdgcn_s_memrealtime();
-        a->trace[4 * s + 2] = tr_spins; a->trace[4 * s + 3] = tr_first;
     }
     DBG16(3, 40);
     // ---- strip epilogue ----
