@@ -280,15 +280,27 @@ int mi355sw_unset_sequences(mi355sw_handle* h) {
 // ------------------------------------------------------------------------------------------------
 // streaming form
 // ------------------------------------------------------------------------------------------------
+// Strip geometry and persistent-wave count (measured on MI355X, tools/gpu_perf.py sweeps):
+//  * strip height 64*R: taller strips amortise the per-step hand-off, shorter ones shorten the pipeline;
+//  * waves: the strip pipeline's start-up cost grows with the square of the wave count, while two
+//    wavefronts per SIMD already keep the VALU busy; very tall partitions (hundreds of rounds) prefer
+//    four per SIMD and 1024-row strips.
 static int pick_rows_per_lane(const mi355sw_handle* h, int m) {
     if (h->cfg.rows_per_lane == 4 || h->cfg.rows_per_lane == 8 || h->cfg.rows_per_lane == 16)
         return h->cfg.rows_per_lane;
-    // enough strips to give every SIMD several wavefronts; taller strips amortise hand-offs
-    const long long slots = (long long) h->compute_units * 16;
-    if ((long long) m >= slots * 64 * 16 * 4) return 16;
-    if ((long long) m >= slots * 64 * 8) return 8;
-    if (m > 64 * 4 * 8) return 4;
+    if (m >= (16 << 20)) return 16;
+    if (m >= 64 * 8 * 64) return 8;
     return 4;
+}
+
+static int pick_waves(const mi355sw_handle* h, int m, int strips) {
+    int waves = h->cfg.waves;
+    if (waves <= 0) {
+        const int simds = h->compute_units * 4;
+        waves = (m >= (16 << 20)) ? simds * 4 : simds * 2;
+    }
+    if (waves > strips) waves = strips;
+    return waves < 1 ? 1 : waves;
 }
 
 int mi355sw_stream_begin(mi355sw_handle* h, const mi355sw_partition* part, const mi355sw_stream_params* p) {
@@ -307,8 +319,7 @@ int mi355sw_stream_begin(mi355sw_handle* h, const mi355sw_partition* part, const
     h->R = pick_rows_per_lane(h, m);
     h->SH = 64 * h->R;
     h->strips = (m + h->SH - 1) / h->SH;
-    int waves = h->cfg.waves > 0 ? h->cfg.waves : h->compute_units * 16;
-    if (waves > h->strips) waves = h->strips;
+    const int waves = pick_waves(h, m, h->strips);
     h->waves = waves;
     h->finished = false;
     h->fed_rows = 0;

@@ -17,10 +17,12 @@
 //   E = sat(pk_max(TL,E) - 2) ; F = sat(pk_max(upT,upF) - 2)     (max(Hl-5,E-2) = max(Tl,E)-2)
 //   H = pk_max(pk_max(pk_max(diag+y, E), F), Z)                  Z = T-domain zero level
 //   T = H - 3
-// 11 packed ops per 2 cells (+1 for the running maximum).  Values are 16-bit relative to a wave-uniform
-// bias (0 in this round): a per-chunk guard on the running maximum reports MI355SW overflow long before a
-// wrap is possible (growth per chunk <= 64), and the host falls back to the int32 kernel.  -INF borders
-// saturate at -32768 and stay there (saturating -2).
+// 11 packed ops per 2 cells (+1 for the running maximum).  Values are 16-bit RELATIVE to a wave-uniform
+// int32 bias that is re-centred at chunk boundaries (every 64 columns) on the wavefront's running maximum:
+// H is Lipschitz (|dH| <= 5 per row/column step), so everything a wavefront touches in one chunk lies
+// within a few thousand of that maximum while the 16-bit window is 65536 wide.  A per-chunk guard on the
+// chunk maximum still reports an overflow (the host then re-runs with the int32 kernel) long before a wrap
+// is possible.  -INF borders saturate at -32768 and stay there (saturating adds).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -33,6 +35,8 @@ namespace mi355sw {
 #define NEG_INF (-999999999)
 #define T_OFF 3            // T = H - 3
 #define PRIO_CHUNKS 4       // chunks of every strip that run at raised wave priority
+#define REBASE_HI 20000     // chunk maximum (relative) above which the window is moved up ...
+#define REBASE_TO 8000      // ... so that the maximum sits here
 #define GUARD16 30000      // chunk maximum above this => overflow report (wrap needs 32767)
 
 typedef unsigned int u32;
@@ -79,6 +83,7 @@ enum { WIN = 128 };   // seq1 window: 128 columns of history in front of the 64-
 struct __attribute__((aligned(16))) WaveLds16 {
     int2 in_tf[CHUNK + 1];      // (T16<<16, F16<<16) of the row above (value in the HIGH half: DPP `old` of lane 0)
     int2 out_tf[CHUNK];         // packed (T,F) words of the emit lane, one per step
+    int2 dump[64];              // write-only slots of the non-emitting lanes (no EXEC toggling per step)
     int c1w[WIN + CHUNK + 8];   // per column j: mask(j) | mask(j-1)<<16
     int red[3 * 64];
 };
@@ -98,7 +103,7 @@ __device__ __forceinline__ void wave_step16(Lane16<R>& st, WaveLds16* lds, const
                                             const int jl /* LO column of this lane at u=0 */, const int n,
                                             const int nvalid_lo, const int nvalid_hi, const int emit_lane,
                                             const int emit_row, const s2 Z, const int bias, int2& feed_io, int& c1_io,
-                                            s2& chunk_max) {
+                                            s2& chunk_max, int2* out_base, const int out_stride) {
     const int2 feed = feed_io;
     const int c1p = c1_io;
     feed_io = lds->in_tf[u + 1];
@@ -159,7 +164,8 @@ __device__ __forceinline__ void wave_step16(Lane16<R>& st, WaveLds16* lds, const
         st.fbot = upF;
     }
     if (!EMIT_ANY) { t_emit = upT; f_emit = upF; }
-    if (lane == emit_lane) lds->out_tf[u] = make_int2(as_i(t_emit), as_i(f_emit));
+    // all lanes store (no s_and_saveexec / s_or per step): lane `emit_lane` into out_tf[u], the others into dump[lane]
+    out_base[out_stride * u] = make_int2(as_i(t_emit), as_i(f_emit));
     chunk_max = pmax(chunk_max, ms);
 
     if (TRACK) {
@@ -194,9 +200,11 @@ __device__ __forceinline__ void run_chunk16(Lane16<R>& st, WaveLds16* lds, const
                                             const int emit_row, const s2 Z, const int bias, s2& cmax) {
     int2 feed = lds->in_tf[0];
     int c1 = lds->c1w[WIN - 2 * lane];
-#pragma unroll 2
+    int2* out_base = (lane == emit_lane) ? &lds->out_tf[0] : &lds->dump[lane];
+    const int out_stride = (lane == emit_lane) ? 1 : 0;
+#pragma unroll 4
     for (int u = 0; u < CHUNK; u++)
-        wave_step16<R, MASKED, TRACKSTEP, EMIT_ANY>(st, lds, u, lane, jl, n, nvalid_lo, nvalid_hi, emit_lane, emit_row, Z, bias, feed, c1, cmax);
+        wave_step16<R, MASKED, TRACKSTEP, EMIT_ANY>(st, lds, u, lane, jl, n, nvalid_lo, nvalid_hi, emit_lane, emit_row, Z, bias, feed, c1, cmax, out_base, out_stride);
 }
 
 template <int R, bool TRACK>
@@ -206,8 +214,7 @@ __device__ __attribute__((noinline)) void process_strip16(const KernelArgs* ap, 
     const int n = a->n;
     const int SH = 128 * R;
     const int nchunks = (n + 127 + CHUNK - 1) / CHUNK;
-    const int bias = 0;                                   // wave-uniform 16-bit bias (fixed this round)
-    const s2 Z = splat(clamp16(0 - bias));                // H-domain zero level of the SW clamp
+    int bias = 0;                                         // wave-uniform int32 bias of the 16-bit window
 
     const int row0 = a->strip_row0 + s * SH;
     const int lrow_lo = row0 + (2 * lane) * R;            // first row of the LO block
@@ -254,9 +261,10 @@ __device__ __attribute__((noinline)) void process_strip16(const KernelArgs* ap, 
         if (spins >= (1 << 26) && lane == 0) atomicExch(a->error_flag, 2);
     }
     Lane16<R> st;
+    int h0[2 * R], e0[2 * R];
+    int hmax = 0;
 #pragma unroll
     for (int r = 0; r < R; r++) {
-        int t[2], e[2], mk[2];
 #pragma unroll
         for (int half = 0; half < 2; half++) {
             const int g = (half ? lrow_hi : lrow_lo) + r;
@@ -265,14 +273,26 @@ __device__ __attribute__((noinline)) void process_strip16(const KernelArgs* ap, 
                 const int2 c = ld_sys2_16(&a->first_col[g + 1]);
                 h = c.x; ee = c.y;
             }
-            if (h - T_OFF - bias > GUARD16) overflow = true;
-            t[half] = clamp16(h - T_OFF - bias);
-            e[half] = clamp16(ee - bias);
+            h0[2 * r + half] = h; e0[2 * r + half] = ee;
+            hmax = max(hmax, h);
+        }
+    }
+    // initial window: centred on the largest first-column score of the strip (0 for zero borders)
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) hmax = max(hmax, __shfl_xor(hmax, d));
+    bias = __builtin_amdgcn_readfirstlane(hmax > REBASE_HI ? hmax - REBASE_TO : 0);
+    s2 Z = splat(clamp16(0 - bias));                      // H-domain zero level of the SW clamp
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        int mk[2];
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+            const int g = (half ? lrow_hi : lrow_lo) + r;
             const int c0 = (g < a->m) ? (int) a->seq0[g] : a->pad_code;
             mk[half] = (c0 < a->n_match_codes) ? (4 << c0) : 0;
         }
-        st.TL[r] = as_s2(pack(t[0], t[1]));
-        st.E[r] = as_s2(pack(e[0], e[1]));
+        st.TL[r] = as_s2(pack(clamp16(h0[2 * r] - T_OFF - bias), clamp16(h0[2 * r + 1] - T_OFF - bias)));
+        st.E[r] = as_s2(pack(clamp16(e0[2 * r] - bias), clamp16(e0[2 * r + 1] - bias)));
         st.M0[r] = pack(mk[0], mk[1]);
     }
     {
@@ -289,7 +309,7 @@ __device__ __attribute__((noinline)) void process_strip16(const KernelArgs* ap, 
     st.tbot = splat(-32768);
     st.fbot = splat(-32768);
     st.best_t = NEG_INF; st.best_r = 2 * R; st.best_j = -1;
-    s2 lane_max = splat(-32768);
+    int lane_max = NEG_INF;                               // best H-3 of this lane, true 32-bit
     int gseen = NEG_INF;
 
     // seq1 window starts empty
@@ -364,6 +384,7 @@ __device__ __attribute__((noinline)) void process_strip16(const KernelArgs* ap, 
         const int jl = col0 - 2 * lane;
         const bool masked = (col0 - 127 < 0) || (col0 + CHUNK - 1 >= n);
         s2 cmax = splat(-32768);
+        int rebias_to = bias;
         // Fast pass: no position bookkeeping at all.  Only if some lane's chunk maximum reaches its
         // (globally seeded) threshold is the chunk replayed from a register snapshot with the exact
         // per-step bookkeeping -- a rare event once the running best is above the background level.
@@ -389,17 +410,26 @@ __device__ __attribute__((noinline)) void process_strip16(const KernelArgs* ap, 
         }
         if (trc) q3 = __builtin_amdgcn_s_memrealtime();
         DBG16(3, 30);
-        lane_max = pmax(lane_max, cmax);
-        // 16-bit range guard (wave-uniform) and publication of a new global best
+        // chunk maximum: range guard, publication of a new global best, re-centring of the 16-bit window
         {
             const int cm = as_i(cmax);
             const int cmv = max(lo16(cm), hi16(cm));
             if (cmv > GUARD16) overflow = true;
-            if (TRACK && __any(cmv + bias > gseen)) {
-                int w = cmv + bias;
+            lane_max = max(lane_max, cmv + bias);
+            int w = cmv;
 #pragma unroll
-                for (int d = 32; d >= 1; d >>= 1) w = max(w, __shfl_xor(w, d));
-                if (lane == 0) atomicMax(a->gbest, w);
+            for (int d = 32; d >= 1; d >>= 1) w = max(w, __shfl_xor(w, d));
+            const int wmax = __builtin_amdgcn_readfirstlane(w);
+            if (TRACK && wmax + bias > gseen) {
+                if (lane == 0) atomicMax(a->gbest, wmax + bias);
+            }
+            int nb = bias;
+            if (wmax > REBASE_HI) nb = bias + (wmax - REBASE_TO);
+            else if (wmax < 0 && bias > 0 && wmax > -32768) nb = max(0, bias + max(wmax - REBASE_TO, -30000));
+            if (nb != bias) {
+                // shift every live 16-bit value by the same amount (saturating: the -INF image stays put
+                // when the window moves up); outputs of this chunk were produced with the old bias
+                rebias_to = nb;
             }
         }
         // (3) output chunk: columns col0-emit_v .. col0-emit_v+63
@@ -424,6 +454,19 @@ __device__ __attribute__((noinline)) void process_strip16(const KernelArgs* ap, 
             if (done > n) done = n;
             if (done < 0) done = 0;
             if (lane == 0) st_agent16(prog_out, done);
+        }
+        if (rebias_to != bias) {
+            const s2 dlt = splat(rebias_to - bias);
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                st.TL[r] = __builtin_elementwise_sub_sat(st.TL[r], dlt);
+                st.E[r] = __builtin_elementwise_sub_sat(st.E[r], dlt);
+            }
+            st.tup_prev = __builtin_elementwise_sub_sat(st.tup_prev, dlt);
+            st.tbot = __builtin_elementwise_sub_sat(st.tbot, dlt);
+            st.fbot = __builtin_elementwise_sub_sat(st.fbot, dlt);
+            bias = rebias_to;
+            Z = splat(clamp16(0 - bias));
         }
         if (trc && lane == 0) {
             q4 = __builtin_amdgcn_s_memrealtime();
@@ -478,16 +521,15 @@ __device__ __attribute__((noinline)) void process_strip16(const KernelArgs* ap, 
     } else {
         // value-only record: the strip's best score; the exact canonical cell of the winning strip is
         // recomputed afterwards from the nearest checkpoint row by the exact-tracking kernel (runtime.cpp)
-        const int lm = as_i(lane_max);
-        lds->red[lane] = max(lo16(lm), hi16(lm));
+        lds->red[lane] = lane_max;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         if (lane == 0) {
-            int bt = -32768;
+            int bt = NEG_INF;
             for (int k = 0; k < 64; k++) bt = max(bt, lds->red[k]);
             int4 rec;
-            rec.x = (bt > -32768) ? bt + T_OFF + bias : NEG_INF;
+            rec.x = (bt > NEG_INF) ? bt + T_OFF : NEG_INF;
             rec.y = -1; rec.z = -1; rec.w = 2;
             a->strip_best[s] = rec;
         }

@@ -194,3 +194,43 @@ def test_large_roundtrip_properties(pkg, aligner):
     assert a[2] >= 400 and a[2] == c[2]
     assert (a[0], a[1]) == (c[1], c[0])
     assert abs(a[0] - 200400) <= 40 and abs(a[1] - 120400) <= 40
+
+
+def test_packed_kernel_rebasing_beyond_16bit(pkg, oracle):
+    """scores above 32767: the packed 16-bit kernel must keep its window centred on the wavefront (re-basing)
+    and stay bit-exact -- best cell, last row and last column -- and must agree with the int32 kernel."""
+    m, n = 70000, 66000
+    s0, s1 = pkg.seqgen.related_pair(m, n, cfg=97)
+    ref = oracle.stage1(s0, s1, want_last_row=True, want_last_col=True)
+    assert ref["best"][2] > 40000
+    for flags, kernel in ((0, 2), (2, 1)):
+        al = pkg.MI355Aligner(device=0, flags=flags)
+        try:
+            al.setSequences(s0, s1)
+            part = pkg.Partition(0, 0, m, n)
+            mg = pkg.Stage1Manager(part, keep_last_row=True, keep_last_column=True)
+            al.alignPartition(part, mg)
+            assert al.getStatistics()["profile_kernel"] == kernel
+            assert tuple(mg.getBestScore()) == tuple(ref["best"])
+            assert np.array_equal(mg.lastRow(), ref["last_row"])
+            assert np.array_equal(mg.lastColumn(), ref["last_col"])
+        finally:
+            al.close()
+
+
+def test_two_phase_exact_position(pkg, oracle, monkeypatch):
+    """value-only main pass + exact re-run of the winning strip from a checkpoint row (used for very tall
+    partitions) gives the same canonical cell as the single pass."""
+    monkeypatch.setenv("MI355SW_TWO_PHASE", "1")
+    for (m, n, rel) in [(9000, 7000, False), (20000, 9000, True), (5000, 30000, False)]:
+        s0, s1 = (pkg.seqgen.related_pair if rel else pkg.seqgen.unrelated_pair)(m, n, cfg=61)
+        al = pkg.MI355Aligner(device=0, rows_per_lane=4)
+        try:
+            al.setSequences(s0, s1)
+            part = pkg.Partition(0, 0, m, n)
+            mg = pkg.Stage1Manager(part)
+            al.alignPartition(part, mg)
+            assert al.getStatistics()["kernel_launches"] == 2
+            assert tuple(mg.getBestScore()) == tuple(oracle.stage1(s0, s1)["best"])
+        finally:
+            al.close()

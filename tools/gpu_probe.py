@@ -55,6 +55,9 @@ if __name__ == "__main__":
             allok &= check(m, n, R=R, force_int32=True)
     allok &= check(4000, 3000, rec=pkg.NEEDLEMAN_WUNSCH, first_row_init_type=pkg.INIT_WITH_GAPS, first_column_init_type=pkg.INIT_WITH_GAPS, R=8)
     allok &= check(20000, 20000, related=False, R=8)
+    allok &= check(70000, 66000, related=True, R=8)
+    allok &= check(70000, 66000, related=True, R=16)
+    allok &= check(50000, 90000, related=True, R=4)
     print("ALL OK" if allok else "SOME FAILED", flush=True)
     if allok and len(sys.argv) > 1:
         perf(200000, 200000, R=8)
