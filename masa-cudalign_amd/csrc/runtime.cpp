@@ -788,17 +788,19 @@ int mi355sw_align_partition(mi355sw_handle* h, const mi355sw_partition* part, co
     }
     if (mg->must_continue && !mg->must_continue(user)) return MI355SW_OK;
 
-    // The packed 16-bit kernel may leave its exact range (reported, never silent).  Nothing is dispatched
-    // to the manager before it has finished cleanly, so that the partition can be re-run with the int32
-    // kernel; partitions that need progressive traffic (streamed first column, last-column matching with
-    // early stop: the stage-2/3 re-entry) go to the int32 kernel directly.
-    bool force32 = (orig_col_type != MI355SW_INIT_WITH_ZEROES) || sp.want_last_column;
+    // The packed 16-bit kernel re-centres its window on the wavefront, but should it ever leave its exact
+    // range this is reported, never silent.  When the partition needs no progressive traffic nothing is
+    // dispatched before the kernel has finished cleanly and the partition is simply re-run with the int32
+    // kernel; with progressive traffic (streamed first column, last-column matching with early stop) the
+    // overflow is returned to the caller as MI355SW_EOVERFLOW16 (retry with MI355SW_F_FORCE_INT32).
+    const bool progressive = (orig_col_type != MI355SW_INIT_WITH_ZEROES) || sp.want_last_column;
+    bool force32 = false;
     int rc = MI355SW_OK;
     for (int attempt = 0; attempt < 2; attempt++) {
     sp.force_int32 = force32 ? 1 : 0;
     rc = mi355sw_stream_begin(h, part, &sp);
     if (rc) return rc;
-    const bool deferred = h->use16;
+    const bool deferred = h->use16 && !progressive;
     const int SH = h->SH;
     std::vector<mi355sw_cell> buf((size_t) std::max(SH, 1 << 16));
     int fed = 0, col_sent = 0, special_sent = 0;

@@ -95,10 +95,10 @@ def test_generic_compare_kernel_and_foreign_bytes(pkg, oracle):
             assert np.array_equal(mg.lastRow(), ref["last_row"])
         finally:
             al.close()
-    # ACGT+N pair with the profile kernels forced off must agree with the profile kernels
+    # ACGT+N pair: packed 16-bit kernel, int32 profile kernel and int32 raw-compare kernel must agree
     s0, s1 = make_pair(pkg, dict(kind="with_n", m=3000, n=3100, cfg=9))
     res = []
-    for flags in (0, 1):
+    for flags in (0, 2, 1):
         al = pkg.MI355Aligner(device=0, flags=flags)
         al.setSequences(s0, s1)
         part = pkg.Partition(0, 0, len(s0), len(s1))
@@ -106,8 +106,9 @@ def test_generic_compare_kernel_and_foreign_bytes(pkg, oracle):
         al.alignPartition(part, mg)
         res.append((al.getStatistics()["profile_kernel"], tuple(mg.getBestScore()), mg.lastColumn()))
         al.close()
-    assert res[0][0] == 1 and res[1][0] == 0
-    assert res[0][1] == res[1][1] and np.array_equal(res[0][2], res[1][2])
+    assert [r[0] for r in res] == [2, 1, 0]
+    for r in res[1:]:
+        assert res[0][1] == r[1] and np.array_equal(res[0][2], r[2])
 
 
 def test_tie_break_canonical_position(pkg, oracle, aligner):
