@@ -286,19 +286,21 @@ int mi355sw_unset_sequences(mi355sw_handle* h) {
 //    wavefronts per SIMD already keep the VALU busy; very tall partitions (hundreds of rounds) prefer
 //    four per SIMD and 1024-row strips.
 static int pick_rows_per_lane(const mi355sw_handle* h, int m) {
-    if (h->cfg.rows_per_lane == 4 || h->cfg.rows_per_lane == 8 || h->cfg.rows_per_lane == 16)
+    if (h->cfg.rows_per_lane == 4 || h->cfg.rows_per_lane == 8 || h->cfg.rows_per_lane == 16 ||
+        h->cfg.rows_per_lane == 32)
         return h->cfg.rows_per_lane;
-    if (m >= (16 << 20)) return 16;
-    if (m >= 64 * 8 * 64) return 8;
+    // one wavefront per SIMD saturates the VALU (a wave64 op holds the 16-lane ALU for 4 cycles), so the
+    // pipeline is kept as short as possible: #SIMDs wavefronts, and strips as tall as leaves >= ~3 rounds
+    const long long simds = (long long) h->compute_units * 4;
+    if ((long long) m >= simds * 2048 * 3) return 32;     // packed kernel only (the int32 kernels cap at 16)
+    if ((long long) m >= simds * 1024 * 2) return 16;
+    if ((long long) m >= simds * 512 * 2) return 8;
     return 4;
 }
 
 static int pick_waves(const mi355sw_handle* h, int m, int strips) {
     int waves = h->cfg.waves;
-    if (waves <= 0) {
-        const int simds = h->compute_units * 4;
-        waves = (m >= (16 << 20)) ? simds * 4 : simds * 2;
-    }
+    if (waves <= 0) waves = h->compute_units * 4;     // one per SIMD (see pick_rows_per_lane)
     if (waves > strips) waves = strips;
     return waves < 1 ? 1 : waves;
 }
@@ -317,6 +319,11 @@ int mi355sw_stream_begin(mi355sw_handle* h, const mi355sw_partition* part, const
     const int m = part->i1 - part->i0, n = part->j1 - part->j0;
     h->m = m; h->n = n;
     h->R = pick_rows_per_lane(h, m);
+    {
+        const bool will16 = (p->recurrence_type == MI355SW_SMITH_WATERMAN) && h->profile && !p->force_int32 &&
+                            !(h->cfg.flags & MI355SW_F_FORCE_INT32);
+        if (h->R == 32 && !will16) h->R = 16;   // the int32 kernels are instantiated for R in {4,8,16}
+    }
     h->SH = 64 * h->R;
     h->strips = (m + h->SH - 1) / h->SH;
     const int waves = pick_waves(h, m, h->strips);

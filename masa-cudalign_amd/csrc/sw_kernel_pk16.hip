@@ -135,7 +135,7 @@ __device__ __forceinline__ void wave_step16(Lane16<R>& st, WaveLds16* lds, const
         s2 Ev = padd_sat(pmax(st.TL[r], st.E[r]), m2);
         s2 Fv = padd_sat(pmax(upT, upF), m2);
         const s2 v = diag + __builtin_bit_cast(s2, y);
-        const s2 H = pmax(pmax(pmax(v, Ev), Fv), Z);
+        const s2 H = pmax(pmax(v, Ev), pmax(Fv, Z));       // (v,E) side is off the row-to-row critical chain
         s2 T = H + m3;
         diag = st.TL[r];
         if (MASKED) {
@@ -594,6 +594,7 @@ hipError_t launch_strip_kernel_pk16(const KernelArgs& a, KernelArgs* dargs, int 
     case 2: if (track) LAUNCH16(2, true); else LAUNCH16(2, false); break;
     case 4: if (track) LAUNCH16(4, true); else LAUNCH16(4, false); break;
     case 8: if (track) LAUNCH16(8, true); else LAUNCH16(8, false); break;
+    case 16: if (track) LAUNCH16(16, true); else LAUNCH16(16, false); break;
     default: return hipErrorInvalidValue;
     }
 #undef LAUNCH16

@@ -50,7 +50,7 @@ def perf(m, n, R=0, waves=0):
 if __name__ == "__main__":
     allok = True
     for (m, n) in [(100, 90), (513, 700), (5000, 4321), (2048, 64), (1, 1), (3000, 10000), (1025, 130), (257, 3)]:
-        for R in (4, 8, 16):
+        for R in (4, 8, 16, 32):
             allok &= check(m, n, R=R)
             allok &= check(m, n, R=R, force_int32=True)
     allok &= check(4000, 3000, rec=pkg.NEEDLEMAN_WUNSCH, first_row_init_type=pkg.INIT_WITH_GAPS, first_column_init_type=pkg.INIT_WITH_GAPS, R=8)
