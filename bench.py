@@ -29,8 +29,11 @@ HBM_PEAK_GBS = 8000.0                 # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # per 4 cycles per SIMD, i.e. 0.59 wave-instructions/ns/SIMD at the 2.38 GHz the chip holds under this load
 VALU_PEAK_WAVE_INSTR = 256 * 4 * 0.59e9
 # VALU instructions per wave-step (SQ_INSTS_VALU / steps; one step = strip_rows cells)
+# HBM-side traffic of one launch from the PMC passes (profiles/r01_pk16_hbm_pmc.json: FETCH_SIZE x2 gfx950
+# correction + WRITE_SIZE), keyed by (kernel, m, n, strip_rows); other configurations report null
+PMC_TRAFFIC_BYTES = {("pk16", 3000000, 3000000, 1024): 170680920384.0}
 VALU_PER_STEP = {("int32", 256): 47.0, ("int32", 512): 86.3, ("int32", 1024): 165.0,
-                 ("pk16", 256): 35.0, ("pk16", 512): 59.0, ("pk16", 1024): 107.0}
+                 ("pk16", 256): 35.0, ("pk16", 512): 59.0, ("pk16", 1024): 105.8, ("pk16", 2048): 200.0}
 
 
 def cpu_baseline(pkg, seconds_budget=20.0):
@@ -181,7 +184,10 @@ def main():
                        "comm": comm if world > 1 else "none"},
             "best": {"i": best[0] + 1, "j": best[1] + 1, "score": best[2]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": (PMC_TRAFFIC_BYTES.get(("pk16" if st["profile_kernel"] == 2 else "int32", m, n,
+                                                            st["strip_rows"])) if world == 1 else None),
+                         "traffic_unit": "bytes per launch (rocprofv3 PMC, profiles/r01_pk16_hbm_pmc.json)",
                          "kernel": "sw_strip_kernel_pk16" if st["profile_kernel"] == 2 else "sw_strip_kernel",
                          "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_bytes,
                          "note": "scan kernel: 17 B per column per %d-row strip; the binding unit is VALU issue" % st["strip_rows"]},
