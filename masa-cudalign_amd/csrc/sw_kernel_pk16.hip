@@ -11,13 +11,17 @@
 // block receives its own lane's LO bottom of the previous step; one v_alignbit_b32 merges the two.
 // Strip height = 128*R rows.
 //
-// Arithmetic (T = H-3 domain, exact restatement of CPUBlockProcessor.cpp:66-93 for SW):
-//   x = mask0[r] & mask1        one-hot base masks (bit 2+code), both halves at once
-//   y = pk_min_u16(x, 4)        = 4 on match, 0 otherwise        (score+3)
-//   E = sat(pk_max(TL,E) - 2) ; F = sat(pk_max(upT,upF) - 2)     (max(Hl-5,E-2) = max(Tl,E)-2)
-//   H = pk_max(pk_max(pk_max(diag+y, E), F), Z)                  Z = T-domain zero level
-//   T = H - 3
-// 11 packed ops per 2 cells (+1 for the running maximum).  Values are 16-bit RELATIVE to a wave-uniform
+// Arithmetic (exact restatement of CPUBlockProcessor.cpp:66-93 for SW).  Row r of a block is kept in the
+// domain X^ = X + 2r - bias ("row-shifted"): stepping DOWN one row then costs nothing for the gap extension
+// (F^[r] = max(T^[r-1], F^[r-1]) is max(Hu-5, Fu-2) in that domain), the SW floor becomes a per-row
+// constant Z^[r] = 2r - bias, and the diagonal score absorbs the shift:
+//   x = mask0[r] & mask1        one-hot base masks (bit 2+code) | bit 1, both halves at once
+//   y = pk_min_u16(x, 6)        = 6 on match, 2 otherwise        (score + 3 + 2)
+//   E = sat(pk_max(TL,E) - 2)                                    (max(Hl-5,E-2) = max(Tl,E)-2, same row)
+//   g = pk_max(pk_max(diag+y, E), Z^[r])                         off the row-to-row dependency chain
+//   F = pk_max(upT, upF) ; H = pk_max(g, F) ; T = H - 3          the chain: 3 dependent ops per row
+// 10 packed ops per 2 cells (+1 for the running maximum).  Bottoms are handed to the next block converted
+// to its "row -1" domain (-2R).  Values are 16-bit RELATIVE to a wave-uniform
 // int32 bias that is re-centred at chunk boundaries (every 64 columns) on the wavefront's running maximum:
 // H is Lipschitz (|dH| <= 5 per row/column step), so everything a wavefront touches in one chunk lies
 // within a few thousand of that maximum while the 16-bit window is 65536 wide.  A per-chunk guard on the
@@ -102,8 +106,8 @@ template <int R, bool MASKED, bool TRACK, bool EMIT_ANY>
 __device__ __forceinline__ void wave_step16(Lane16<R>& st, WaveLds16* lds, const int u, const int lane,
                                             const int jl /* LO column of this lane at u=0 */, const int n,
                                             const int nvalid_lo, const int nvalid_hi, const int emit_lane,
-                                            const int emit_row, const s2 Z, const int bias, int2& feed_io, int& c1_io,
-                                            s2& chunk_max, int2* out_base, const int out_stride) {
+                                            const int emit_row, const s2 (&Z)[R], const int bias, int2& feed_io, int& c1_io,
+                                            s2 (&cm)[R], int2* out_base, const int out_stride) {
     const int2 feed = feed_io;
     const int c1p = c1_io;
     feed_io = lds->in_tf[u + 1];
@@ -124,18 +128,20 @@ __device__ __forceinline__ void wave_step16(Lane16<R>& st, WaveLds16* lds, const
         vmask = (vlo ? 0xffff : 0) | (vhi ? 0xffff0000 : 0);
     }
     const s2 m2 = splat(-2), m3 = splat(-T_OFF);
-    const us2 four = {4, 4};
+    const us2 six = {6, 6};
     s2 t_emit = splat(0), f_emit = splat(0);
-    s2 ms = splat(-32768);
+    s2 ms = splat(-32768);                                   // TRACK only: true (unshifted) maximum of the step
     s2 newT[R];
+    s2 Hbot = splat(0);
 #pragma unroll
     for (int r = 0; r < R; r++) {
         const int x = st.M0[r] & c1p;
-        const us2 y = __builtin_elementwise_min(__builtin_bit_cast(us2, x), four);
+        const us2 y = __builtin_elementwise_min(__builtin_bit_cast(us2, x), six);
         s2 Ev = padd_sat(pmax(st.TL[r], st.E[r]), m2);
-        s2 Fv = padd_sat(pmax(upT, upF), m2);
         const s2 v = diag + __builtin_bit_cast(s2, y);
-        const s2 H = pmax(pmax(v, Ev), pmax(Fv, Z));       // (v,E) side is off the row-to-row critical chain
+        const s2 g = pmax(pmax(v, Ev), Z[r]);              // off the row-to-row critical chain
+        const s2 Fv = pmax(upT, upF);                      // chain: max, max, add per row
+        const s2 H = pmax(g, Fv);
         s2 T = H + m3;
         diag = st.TL[r];
         if (MASKED) {
@@ -147,26 +153,35 @@ __device__ __forceinline__ void wave_step16(Lane16<R>& st, WaveLds16* lds, const
         newT[r] = T;
         upT = T;
         upF = Fv;
-        if (MASKED) ms = pmax(ms, as_s2((as_i(T) & vmask) | (0x80008000 & ~vmask)));
-        else ms = pmax(ms, T);
+        Hbot = H;
+        if (MASKED) cm[r] = pmax(cm[r], as_s2((as_i(T) & vmask) | (0x80008000 & ~vmask)));
+        else cm[r] = pmax(cm[r], T);
+        if (TRACK) {
+            const s2 tt = T + splat(-2 * r);
+            if (MASKED) ms = pmax(ms, as_s2((as_i(tt) & vmask) | (0x80008000 & ~vmask)));
+            else ms = pmax(ms, tt);
+        }
         if (EMIT_ANY) {
             t_emit = (r == emit_row) ? T : t_emit;
             f_emit = (r == emit_row) ? Fv : f_emit;
         }
     }
+    // bottoms for the next block, converted to its "row -1" domain (2(R-1) -> -2); saturating, so the
+    // -INF image stays put.  tbot comes straight from H (parallel to T = H - 3, not behind it).
+    const s2 tb = MASKED ? padd_sat(upT, splat(-2 * R)) : padd_sat(Hbot, splat(-T_OFF - 2 * R));
+    const s2 fb = padd_sat(upF, splat(-2 * R));
     if (MASKED) {
         st.tup_prev = as_s2((as_i(tup) & vmask) | (as_i(st.tup_prev) & ~vmask));
-        st.tbot = as_s2((as_i(upT) & vmask) | (as_i(st.tbot) & ~vmask));
-        st.fbot = as_s2((as_i(upF) & vmask) | (as_i(st.fbot) & ~vmask));
+        st.tbot = as_s2((as_i(tb) & vmask) | (as_i(st.tbot) & ~vmask));
+        st.fbot = as_s2((as_i(fb) & vmask) | (as_i(st.fbot) & ~vmask));
     } else {
         st.tup_prev = tup;
-        st.tbot = upT;
-        st.fbot = upF;
+        st.tbot = tb;
+        st.fbot = fb;
     }
     if (!EMIT_ANY) { t_emit = upT; f_emit = upF; }
     // all lanes store (no s_and_saveexec / s_or per step): lane `emit_lane` into out_tf[u], the others into dump[lane]
     out_base[out_stride * u] = make_int2(as_i(t_emit), as_i(f_emit));
-    chunk_max = pmax(chunk_max, ms);
 
     if (TRACK) {
         // cheap per-step test on max(lo,hi); rare exact path keeps the canonical (max, min i, min j) cell
@@ -181,7 +196,7 @@ __device__ __forceinline__ void wave_step16(Lane16<R>& st, WaveLds16* lds, const
 #pragma unroll
                 for (int r = 0; r < R; r++) {
                     const int w = as_i(newT[r]);
-                    const int t = (half ? hi16(w) : lo16(w)) + bias;
+                    const int t = (half ? hi16(w) : lo16(w)) + bias - 2 * r;
                     const int rr = half * R + r;
                     const bool upd = hv && (r < nv) && ((t > st.best_t) || (t == st.best_t && rr < st.best_r));
                     st.best_t = upd ? t : st.best_t;
@@ -193,11 +208,23 @@ __device__ __forceinline__ void wave_step16(Lane16<R>& st, WaveLds16* lds, const
     }
 }
 
+// true (unshifted) maximum T of a chunk from the per-row accumulators
+template <int R>
+__device__ __forceinline__ int chunk_max16(const s2 (&cm)[R]) {
+    int v = -32768 - 2 * R;
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const int w = as_i(cm[r]);
+        v = max(v, max(lo16(w), hi16(w)) - 2 * r);
+    }
+    return v;
+}
+
 // 64 systolic steps of one chunk (reads the staged inputs from LDS, leaves the emit row in out_tf)
 template <int R, bool MASKED, bool TRACKSTEP, bool EMIT_ANY>
 __device__ __forceinline__ void run_chunk16(Lane16<R>& st, WaveLds16* lds, const int lane, const int jl, const int n,
                                             const int nvalid_lo, const int nvalid_hi, const int emit_lane,
-                                            const int emit_row, const s2 Z, const int bias, s2& cmax) {
+                                            const int emit_row, const s2 (&Z)[R], const int bias, s2 (&cmax)[R]) {
     int2 feed = lds->in_tf[0];
     int c1 = lds->c1w[WIN - 2 * lane];
     int2* out_base = (lane == emit_lane) ? &lds->out_tf[0] : &lds->dump[lane];
@@ -281,7 +308,9 @@ __device__ __attribute__((noinline)) void process_strip16(const KernelArgs* ap, 
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) hmax = max(hmax, __shfl_xor(hmax, d));
     bias = __builtin_amdgcn_readfirstlane(hmax > REBASE_HI ? hmax - REBASE_TO : 0);
-    s2 Z = splat(clamp16(0 - bias));                      // H-domain zero level of the SW clamp
+    s2 Z[R];                                              // SW floor (H = 0) of every row in its shifted domain
+#pragma unroll
+    for (int r = 0; r < R; r++) Z[r] = splat(clamp16(2 * r - bias));
 #pragma unroll
     for (int r = 0; r < R; r++) {
         int mk[2];
@@ -289,10 +318,10 @@ __device__ __attribute__((noinline)) void process_strip16(const KernelArgs* ap, 
         for (int half = 0; half < 2; half++) {
             const int g = (half ? lrow_hi : lrow_lo) + r;
             const int c0 = (g < a->m) ? (int) a->seq0[g] : a->pad_code;
-            mk[half] = (c0 < a->n_match_codes) ? (4 << c0) : 0;
+            mk[half] = ((c0 < a->n_match_codes) ? (4 << c0) : 0) | 2;   // bit 1: the constant part of the score
         }
-        st.TL[r] = as_s2(pack(clamp16(h0[2 * r] - T_OFF - bias), clamp16(h0[2 * r + 1] - T_OFF - bias)));
-        st.E[r] = as_s2(pack(clamp16(e0[2 * r] - bias), clamp16(e0[2 * r + 1] - bias)));
+        st.TL[r] = as_s2(pack(clamp16(h0[2 * r] - T_OFF - bias + 2 * r), clamp16(h0[2 * r + 1] - T_OFF - bias + 2 * r)));
+        st.E[r] = as_s2(pack(clamp16(e0[2 * r] - bias + 2 * r), clamp16(e0[2 * r + 1] - bias + 2 * r)));
         st.M0[r] = pack(mk[0], mk[1]);
     }
     {
@@ -302,7 +331,7 @@ __device__ __attribute__((noinline)) void process_strip16(const KernelArgs* ap, 
             const int g0 = half ? lrow_hi : lrow_lo;
             int h = 0;
             if (a->first_col != nullptr && g0 <= a->m) h = ld_sys2_16(&a->first_col[g0]).x;
-            hd[half] = clamp16(h - T_OFF - bias);
+            hd[half] = clamp16(h - T_OFF - bias - 2);        // "row -1" of the block
         }
         st.tup_prev = as_s2(pack(hd[0], hd[1]));
     }
@@ -313,8 +342,8 @@ __device__ __attribute__((noinline)) void process_strip16(const KernelArgs* ap, 
     int gseen = NEG_INF;
 
     // seq1 window starts empty
-    lds->c1w[lane] = 0; lds->c1w[64 + lane] = 0; lds->c1w[128 + lane] = 0;
-    if (lane < 8) lds->c1w[192 + lane] = 0;
+    lds->c1w[lane] = 0x00020002; lds->c1w[64 + lane] = 0x00020002; lds->c1w[128 + lane] = 0x00020002;
+    if (lane < 8) lds->c1w[192 + lane] = 0x00020002;
 
     DBG16(1, 1);
     long long tr_start = 0, tr_first = 0; int tr_spins = 0;
@@ -364,8 +393,8 @@ __device__ __attribute__((noinline)) void process_strip16(const KernelArgs* ap, 
                 code = a->seq1[col] >> 2;               // seq1 holds code*4 (shift form of the int32 kernel)
             }
             if (col >= 1 && col - 1 < n) codep = a->seq1[col - 1] >> 2;
-            const int mk = (code < a->n_match_codes) ? (4 << code) : 0;
-            const int mkp = (codep < a->n_match_codes) ? (4 << codep) : 0;
+            const int mk = ((code < a->n_match_codes) ? (4 << code) : 0) | 2;
+            const int mkp = ((codep < a->n_match_codes) ? (4 << codep) : 0) | 2;
             if (hf.x - T_OFF - bias > GUARD16) overflow = true;
             // shift the window by one chunk, then append
             const int w0 = lds->c1w[64 + lane];
@@ -373,7 +402,7 @@ __device__ __attribute__((noinline)) void process_strip16(const KernelArgs* ap, 
             lds->c1w[lane] = w0;
             lds->c1w[64 + lane] = w1;
             lds->c1w[128 + lane] = mk | (mkp << 16);
-            lds->in_tf[lane] = make_int2(clamp16(hf.x - T_OFF - bias) << 16, clamp16(hf.y - bias) << 16);
+            lds->in_tf[lane] = make_int2(clamp16(hf.x - T_OFF - bias - 2) << 16, clamp16(hf.y - bias - 2) << 16);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -383,7 +412,9 @@ __device__ __attribute__((noinline)) void process_strip16(const KernelArgs* ap, 
         // (2) 64 systolic steps
         const int jl = col0 - 2 * lane;
         const bool masked = (col0 - 127 < 0) || (col0 + CHUNK - 1 >= n);
-        s2 cmax = splat(-32768);
+        s2 cmax[R];
+#pragma unroll
+        for (int r = 0; r < R; r++) cmax[r] = splat(-32768);
         int rebias_to = bias;
         // Fast pass: no position bookkeeping at all.  Only if some lane's chunk maximum reaches its
         // (globally seeded) threshold is the chunk replayed from a register snapshot with the exact
@@ -398,12 +429,13 @@ __device__ __attribute__((noinline)) void process_strip16(const KernelArgs* ap, 
         else if (masked) run_chunk16<R, true, false, false>(st, lds, lane, jl, n, nvalid_lo, nvalid_hi, 63, R - 1, Z, bias, cmax);
         else run_chunk16<R, false, false, false>(st, lds, lane, jl, n, nvalid_lo, nvalid_hi, 63, R - 1, Z, bias, cmax);
         if (TRACK) {
-            const int cm0 = as_i(cmax);
-            if (__any(max(lo16(cm0), hi16(cm0)) + bias >= st.best_t)) {
+            if (__any(chunk_max16<R>(cmax) + bias >= st.best_t)) {
 #pragma unroll
                 for (int r = 0; r < R; r++) { st.TL[r] = snap.TL[r]; st.E[r] = snap.E[r]; }
                 st.tup_prev = snap.tup_prev; st.tbot = snap.tbot; st.fbot = snap.fbot;
-                s2 cmax2 = splat(-32768);
+                s2 cmax2[R];
+#pragma unroll
+                for (int r = 0; r < R; r++) cmax2[r] = splat(-32768);
                 if (ragged) run_chunk16<R, true, true, true>(st, lds, lane, jl, n, nvalid_lo, nvalid_hi, emit_lane, emit_row, Z, bias, cmax2);
                 else run_chunk16<R, true, true, false>(st, lds, lane, jl, n, nvalid_lo, nvalid_hi, 63, R - 1, Z, bias, cmax2);
             }
@@ -412,8 +444,7 @@ __device__ __attribute__((noinline)) void process_strip16(const KernelArgs* ap, 
         DBG16(3, 30);
         // chunk maximum: range guard, publication of a new global best, re-centring of the 16-bit window
         {
-            const int cm = as_i(cmax);
-            const int cmv = max(lo16(cm), hi16(cm));
+            const int cmv = chunk_max16<R>(cmax);
             if (cmv > GUARD16) overflow = true;
             lane_max = max(lane_max, cmv + bias);
             int w = cmv;
@@ -443,7 +474,8 @@ __device__ __attribute__((noinline)) void process_strip16(const KernelArgs* ap, 
                 const int t16 = emit_half ? hi16(tf.x) : lo16(tf.x);
                 const int f16 = emit_half ? hi16(tf.y) : lo16(tf.y);
                 // -32768 is the sticky image of -INF (only border rows can carry it)
-                const int2 hf = make_int2(t16 + T_OFF + bias, f16 == -32768 ? NEG_INF : f16 + bias);
+                const int2 hf = make_int2(t16 + T_OFF + bias - 2 * emit_row,
+                                          f16 == -32768 ? NEG_INF : f16 + bias - 2 * emit_row);
                 st_agent2_16(&a->bus[col], hf);
                 if (special != nullptr) special[col] = hf;
                 if (lastrow != nullptr) lastrow[col] = hf;
@@ -466,7 +498,8 @@ __device__ __attribute__((noinline)) void process_strip16(const KernelArgs* ap, 
             st.tbot = __builtin_elementwise_sub_sat(st.tbot, dlt);
             st.fbot = __builtin_elementwise_sub_sat(st.fbot, dlt);
             bias = rebias_to;
-            Z = splat(clamp16(0 - bias));
+#pragma unroll
+            for (int r = 0; r < R; r++) Z[r] = splat(clamp16(2 * r - bias));
         }
         if (trc && lane == 0) {
             q4 = __builtin_amdgcn_s_memrealtime();
@@ -494,7 +527,7 @@ __device__ __attribute__((noinline)) void process_strip16(const KernelArgs* ap, 
                 if (g < a->m) {
                     const int t16 = half ? hi16(as_i(st.TL[r])) : lo16(as_i(st.TL[r]));
                     const int e16 = half ? hi16(as_i(st.E[r])) : lo16(as_i(st.E[r]));
-                    a->last_col[g + 1] = make_int2(t16 + T_OFF + bias, e16 == -32768 ? NEG_INF : e16 + bias);
+                    a->last_col[g + 1] = make_int2(t16 + T_OFF + bias - 2 * r, e16 == -32768 ? NEG_INF : e16 + bias - 2 * r);
                 }
             }
         }
