@@ -41,6 +41,12 @@ namespace mi355sw {
 #define PRIO_CHUNKS 4       // chunks of every strip that run at raised wave priority
 #define REBASE_HI 20000     // chunk maximum (relative) above which the window is moved up ...
 #define REBASE_TO 8000      // ... so that the maximum sits here
+#ifndef PK16_HALFTRACK
+#define PK16_HALFTRACK 1  // fast pass accumulates the chunk maximum on odd rows only (even rows: bound +5)
+#endif
+#ifndef PK16_UNROLL
+#define PK16_UNROLL 4     // steps per loop body of the 64-step chunk loop
+#endif
 #define GUARD16 30000      // chunk maximum above this => overflow report (wrap needs 32767)
 
 typedef unsigned int u32;
@@ -102,7 +108,7 @@ struct Lane16 {
     int best_t, best_r, best_j;   // best T (true, 32-bit), row index inside the lane (0..2R-1), column
 };
 
-template <int R, bool MASKED, bool TRACK, bool EMIT_ANY>
+template <int R, bool MASKED, bool TRACK, bool EMIT_ANY, bool HALF>
 __device__ __forceinline__ void wave_step16(Lane16<R>& st, WaveLds16* lds, const int u, const int lane,
                                             const int jl /* LO column of this lane at u=0 */, const int n,
                                             const int nvalid_lo, const int nvalid_hi, const int emit_lane,
@@ -154,8 +160,12 @@ __device__ __forceinline__ void wave_step16(Lane16<R>& st, WaveLds16* lds, const
         upT = T;
         upF = Fv;
         Hbot = H;
-        if (MASKED) cm[r] = pmax(cm[r], as_s2((as_i(T) & vmask) | (0x80008000 & ~vmask)));
-        else cm[r] = pmax(cm[r], T);
+        // HALF: H(i,j) <= H(i+1,j) + 5 (the row below can always open a gap), so the odd rows bound the
+        // even ones; the chunk test adds the 5 and an exact replay decides
+        if (!HALF || (r & 1)) {
+            if (MASKED) cm[r] = pmax(cm[r], as_s2((as_i(T) & vmask) | (0x80008000 & ~vmask)));
+            else cm[r] = pmax(cm[r], T);
+        }
         if (TRACK) {
             const s2 tt = T + splat(-2 * r);
             if (MASKED) ms = pmax(ms, as_s2((as_i(tt) & vmask) | (0x80008000 & ~vmask)));
@@ -209,11 +219,11 @@ __device__ __forceinline__ void wave_step16(Lane16<R>& st, WaveLds16* lds, const
 }
 
 // true (unshifted) maximum T of a chunk from the per-row accumulators
-template <int R>
+template <int R, bool HALF>
 __device__ __forceinline__ int chunk_max16(const s2 (&cm)[R]) {
     int v = -32768 - 2 * R;
 #pragma unroll
-    for (int r = 0; r < R; r++) {
+    for (int r = HALF ? 1 : 0; r < R; r += HALF ? 2 : 1) {
         const int w = as_i(cm[r]);
         v = max(v, max(lo16(w), hi16(w)) - 2 * r);
     }
@@ -221,7 +231,7 @@ __device__ __forceinline__ int chunk_max16(const s2 (&cm)[R]) {
 }
 
 // 64 systolic steps of one chunk (reads the staged inputs from LDS, leaves the emit row in out_tf)
-template <int R, bool MASKED, bool TRACKSTEP, bool EMIT_ANY>
+template <int R, bool MASKED, bool TRACKSTEP, bool EMIT_ANY, bool HALF>
 __device__ __forceinline__ void run_chunk16(Lane16<R>& st, WaveLds16* lds, const int lane, const int jl, const int n,
                                             const int nvalid_lo, const int nvalid_hi, const int emit_lane,
                                             const int emit_row, const s2 (&Z)[R], const int bias, s2 (&cmax)[R]) {
@@ -229,9 +239,9 @@ __device__ __forceinline__ void run_chunk16(Lane16<R>& st, WaveLds16* lds, const
     int c1 = lds->c1w[WIN - 2 * lane];
     int2* out_base = (lane == emit_lane) ? &lds->out_tf[0] : &lds->dump[lane];
     const int out_stride = (lane == emit_lane) ? 1 : 0;
-#pragma unroll 4
+#pragma unroll PK16_UNROLL
     for (int u = 0; u < CHUNK; u++)
-        wave_step16<R, MASKED, TRACKSTEP, EMIT_ANY>(st, lds, u, lane, jl, n, nvalid_lo, nvalid_hi, emit_lane, emit_row, Z, bias, feed, c1, cmax, out_base, out_stride);
+        wave_step16<R, MASKED, TRACKSTEP, EMIT_ANY, HALF>(st, lds, u, lane, jl, n, nvalid_lo, nvalid_hi, emit_lane, emit_row, Z, bias, feed, c1, cmax, out_base, out_stride);
 }
 
 template <int R, bool TRACK>
@@ -254,7 +264,8 @@ __device__ __attribute__((noinline)) void process_strip16(const KernelArgs* ap, 
     // emitting virtual lane / row: the strip's bottom row, or DP row m-1 for the ragged last strip
     int emit_v = 127, emit_row = R - 1;
     const bool ragged = (row0 + SH > a->m);
-    if (ragged) {
+    const bool emit_any = ragged && a->last_row != nullptr;   // otherwise nobody reads a ragged strip's bus row
+    if (emit_any) {
         const int last = a->m - 1 - row0;
         emit_v = last / R;
         emit_row = last - emit_v * R;
@@ -425,27 +436,32 @@ __device__ __attribute__((noinline)) void process_strip16(const KernelArgs* ap, 
             for (int r = 0; r < R; r++) { snap.TL[r] = st.TL[r]; snap.E[r] = st.E[r]; }
             snap.tup_prev = st.tup_prev; snap.tbot = st.tbot; snap.fbot = st.fbot;
         }
-        if (ragged) run_chunk16<R, true, false, true>(st, lds, lane, jl, n, nvalid_lo, nvalid_hi, emit_lane, emit_row, Z, bias, cmax);
-        else if (masked) run_chunk16<R, true, false, false>(st, lds, lane, jl, n, nvalid_lo, nvalid_hi, 63, R - 1, Z, bias, cmax);
-        else run_chunk16<R, false, false, false>(st, lds, lane, jl, n, nvalid_lo, nvalid_hi, 63, R - 1, Z, bias, cmax);
+        constexpr bool HALF = TRACK && (PK16_HALFTRACK != 0);
+        constexpr int SLACK = HALF ? 5 : 0;                // what an untracked (even) row can exceed its neighbour by
+        // The ragged last strip runs the ordinary code (rows past m are ordinary cells that never match);
+        // only when its DP row m-1 is wanted (last row) does the emit position have to move off the bottom.
+        if (emit_any && masked) run_chunk16<R, true, false, true, HALF>(st, lds, lane, jl, n, nvalid_lo, nvalid_hi, emit_lane, emit_row, Z, bias, cmax);
+        else if (emit_any) run_chunk16<R, false, false, true, HALF>(st, lds, lane, jl, n, nvalid_lo, nvalid_hi, emit_lane, emit_row, Z, bias, cmax);
+        else if (masked) run_chunk16<R, true, false, false, HALF>(st, lds, lane, jl, n, nvalid_lo, nvalid_hi, 63, R - 1, Z, bias, cmax);
+        else run_chunk16<R, false, false, false, HALF>(st, lds, lane, jl, n, nvalid_lo, nvalid_hi, 63, R - 1, Z, bias, cmax);
         if (TRACK) {
-            if (__any(chunk_max16<R>(cmax) + bias >= st.best_t)) {
+            if (__any(chunk_max16<R, HALF>(cmax) + SLACK + bias >= st.best_t)) {
 #pragma unroll
                 for (int r = 0; r < R; r++) { st.TL[r] = snap.TL[r]; st.E[r] = snap.E[r]; }
                 st.tup_prev = snap.tup_prev; st.tbot = snap.tbot; st.fbot = snap.fbot;
                 s2 cmax2[R];
 #pragma unroll
                 for (int r = 0; r < R; r++) cmax2[r] = splat(-32768);
-                if (ragged) run_chunk16<R, true, true, true>(st, lds, lane, jl, n, nvalid_lo, nvalid_hi, emit_lane, emit_row, Z, bias, cmax2);
-                else run_chunk16<R, true, true, false>(st, lds, lane, jl, n, nvalid_lo, nvalid_hi, 63, R - 1, Z, bias, cmax2);
+                if (emit_any) run_chunk16<R, true, true, true, false>(st, lds, lane, jl, n, nvalid_lo, nvalid_hi, emit_lane, emit_row, Z, bias, cmax2);
+                else run_chunk16<R, true, true, false, false>(st, lds, lane, jl, n, nvalid_lo, nvalid_hi, 63, R - 1, Z, bias, cmax2);
             }
         }
         if (trc) q3 = __builtin_amdgcn_s_memrealtime();
         DBG16(3, 30);
         // chunk maximum: range guard, publication of a new global best, re-centring of the 16-bit window
         {
-            const int cmv = chunk_max16<R>(cmax);
-            if (cmv > GUARD16) overflow = true;
+            const int cmv = chunk_max16<R, HALF>(cmax);    // exact, or a lower bound within SLACK of it
+            if (cmv + SLACK > GUARD16) overflow = true;
             lane_max = max(lane_max, cmv + bias);
             int w = cmv;
 #pragma unroll
@@ -455,7 +471,7 @@ __device__ __attribute__((noinline)) void process_strip16(const KernelArgs* ap, 
                 if (lane == 0) atomicMax(a->gbest, wmax + bias);
             }
             int nb = bias;
-            if (wmax > REBASE_HI) nb = bias + (wmax - REBASE_TO);
+            if (wmax + SLACK > REBASE_HI) nb = bias + (wmax - REBASE_TO);
             else if (wmax < 0 && bias > 0 && wmax > -32768) nb = max(0, bias + max(wmax - REBASE_TO, -30000));
             if (nb != bias) {
                 // shift every live 16-bit value by the same amount (saturating: the -INF image stays put
@@ -604,6 +620,11 @@ __global__ void __launch_bounds__(64) sw_strip_kernel_pk16(const KernelArgs* __r
     const int lane = threadIdx.x;
     const UniformArgs a = uniform_args(ap);
     const int num_strips = a->num_strips;
+    // One wavefront per SIMD is the design point and the strip chain runs at the speed of its
+    // slowest member, so placement must not be left to the dispatcher: claiming the top accumulation
+    // register makes the wavefront's register allocation exceed half of the SIMD's 512-entry file, and the
+    // hardware then cannot co-schedule two of them on one SIMD.
+    asm volatile("" ::: "a255");
     for (;;) {
         const int s = __builtin_amdgcn_readfirstlane(claim_strip16(ap, lane));
         if (s >= num_strips) break;

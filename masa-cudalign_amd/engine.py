@@ -12,7 +12,8 @@ import subprocess
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libmi355sw.so")
+# MI355SW_LIB: alternative build of the same library (kernel A/B experiments, tools/gpu_perf.py)
+LIB_PATH = os.environ.get("MI355SW_LIB") or os.path.join(HERE, "libmi355sw.so")
 INCLUDE_PATH = os.path.join(os.path.dirname(HERE), "include", "mi355sw.h")
 
 INF = 999999999
