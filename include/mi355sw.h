@@ -56,7 +56,7 @@ typedef struct mi355sw_handle mi355sw_handle;
 /* Extension parameters; replaces X/CUDAlignerParameters.cpp:33-110 (--gpu, --blocks). */
 typedef struct {
     int32_t device;          /* HIP ordinal, -1 = current device (reference: --gpu)                 */
-    int32_t rows_per_lane;   /* R in {4,8,16,32}; strip height = 64*R (reference: THREADS_COUNT*ALPHA);
+    int32_t rows_per_lane;   /* R in {4,8,12,16,24,32} (12/24/32: packed kernel only); strip height = 64*R (reference: THREADS_COUNT*ALPHA);
                                 0 = choose from the partition size                                 */
     int32_t waves;           /* persistent wavefronts (reference: --blocks); 0 = one per SIMD      */
     int32_t flags;           /* MI355SW_F_*                                                          */

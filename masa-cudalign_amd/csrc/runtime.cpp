@@ -280,27 +280,39 @@ int mi355sw_unset_sequences(mi355sw_handle* h) {
 // ------------------------------------------------------------------------------------------------
 // streaming form
 // ------------------------------------------------------------------------------------------------
-// Strip geometry and persistent-wave count (measured on MI355X, tools/gpu_perf.py sweeps):
-//  * strip height 64*R: taller strips amortise the per-step hand-off, shorter ones shorten the pipeline;
-//  * waves: the strip pipeline's start-up cost grows with the square of the wave count, while two
-//    wavefronts per SIMD already keep the VALU busy; very tall partitions (hundreds of rounds) prefer
-//    four per SIMD and 1024-row strips.
-static int pick_rows_per_lane(const mi355sw_handle* h, int m) {
-    if (h->cfg.rows_per_lane == 4 || h->cfg.rows_per_lane == 8 || h->cfg.rows_per_lane == 16 ||
-        h->cfg.rows_per_lane == 32)
+// Strip geometry (measured on MI355X, tools/gpu_perf.py sweeps, packed kernel, one wavefront per SIMD):
+// one systolic step of a 64*R-row strip costs about 70 + 11.8*R ns (hand-off, LDS traffic and the per-chunk
+// publish/poll are per step, the cell arithmetic per row), a strip follows its predecessor ~280 steps
+// behind, and the W wavefronts sweep the partition in ceil(strips/W) rounds of n steps each -- a partly
+// filled last round costs a full one.  Pick the height with the smallest estimate.
+static double estimate_ns(int m, int n, int R, int W) {
+    const double step = 70.0 + 11.8 * R;
+    const long long strips = ((long long) m + 64 * R - 1) / (64 * R);
+    const long long rounds = (strips + W - 1) / W;
+    const long long hops = strips < W ? strips : W;
+    return step * ((double) rounds * n + 280.0 * hops);
+}
+
+static int pick_rows_per_lane(const mi355sw_handle* h, int m, int n, bool packed) {
+    if (h->cfg.rows_per_lane == 4 || h->cfg.rows_per_lane == 8 || h->cfg.rows_per_lane == 12 ||
+        h->cfg.rows_per_lane == 16 || h->cfg.rows_per_lane == 24 || h->cfg.rows_per_lane == 32)
         return h->cfg.rows_per_lane;
-    // one wavefront per SIMD saturates the VALU (a wave64 op holds the 16-lane ALU for 4 cycles), so the
-    // pipeline is kept as short as possible: #SIMDs wavefronts, and strips as tall as leaves >= ~3 rounds
-    const long long simds = (long long) h->compute_units * 4;
-    if ((long long) m >= simds * 2048 * 3) return 32;     // packed kernel only (the int32 kernels cap at 16)
-    if ((long long) m >= simds * 1024 * 2) return 16;
-    if ((long long) m >= simds * 512 * 2) return 8;
-    return 4;
+    static const int cand16[] = {4, 8, 12, 16, 24, 32}, cand32[] = {4, 8, 16};
+    const int* cand = packed ? cand16 : cand32;
+    const int nc = packed ? 6 : 3;
+    const int W = h->cfg.waves > 0 ? h->cfg.waves : h->compute_units * 4;
+    int best = cand[0];
+    double tb = estimate_ns(m, n, best, W);
+    for (int k = 1; k < nc; k++) {
+        const double t = estimate_ns(m, n, cand[k], W);
+        if (t < tb) { tb = t; best = cand[k]; }
+    }
+    return best;
 }
 
 static int pick_waves(const mi355sw_handle* h, int m, int strips) {
     int waves = h->cfg.waves;
-    if (waves <= 0) waves = h->compute_units * 4;     // one per SIMD (see pick_rows_per_lane)
+    if (waves <= 0) waves = h->compute_units * 4;     // one per SIMD (enforced by the kernels' register allocation)
     if (waves > strips) waves = strips;
     return waves < 1 ? 1 : waves;
 }
@@ -318,11 +330,12 @@ int mi355sw_stream_begin(mi355sw_handle* h, const mi355sw_partition* part, const
     h->sp = *p;
     const int m = part->i1 - part->i0, n = part->j1 - part->j0;
     h->m = m; h->n = n;
-    h->R = pick_rows_per_lane(h, m);
     {
         const bool will16 = (p->recurrence_type == MI355SW_SMITH_WATERMAN) && h->profile && !p->force_int32 &&
                             !(h->cfg.flags & MI355SW_F_FORCE_INT32);
-        if (h->R == 32 && !will16) h->R = 16;   // the int32 kernels are instantiated for R in {4,8,16}
+        h->R = pick_rows_per_lane(h, m, n, will16);
+        // the int32 kernels are instantiated for R in {4,8,16}
+        if (!will16 && h->R != 4 && h->R != 8 && h->R != 16) h->R = h->R > 16 ? 16 : 8;
     }
     h->SH = 64 * h->R;
     h->strips = (m + h->SH - 1) / h->SH;
@@ -338,7 +351,7 @@ int mi355sw_stream_begin(mi355sw_handle* h, const mi355sw_partition* part, const
     if (p->special_row_interval > 0) {
         int K = (p->special_row_interval + h->SH - 1) / h->SH;
         if (K <= 0) K = 1;
-        if (K <= 8192 / h->SH) K = 8192 / h->SH;
+        if (K < (8192 + h->SH - 1) / h->SH) K = (8192 + h->SH - 1) / h->SH;
         if (K < 1) K = 1;
         h->special_interval_strips = K;
         h->n_special = (int) (((long long) m - 1) / ((long long) K * h->SH));   // rows K*SH*k < m

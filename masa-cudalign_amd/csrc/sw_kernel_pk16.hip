@@ -647,7 +647,9 @@ hipError_t launch_strip_kernel_pk16(const KernelArgs& a, KernelArgs* dargs, int 
     switch (rows_per_half) {
     case 2: if (track) LAUNCH16(2, true); else LAUNCH16(2, false); break;
     case 4: if (track) LAUNCH16(4, true); else LAUNCH16(4, false); break;
+    case 6: if (track) LAUNCH16(6, true); else LAUNCH16(6, false); break;
     case 8: if (track) LAUNCH16(8, true); else LAUNCH16(8, false); break;
+    case 12: if (track) LAUNCH16(12, true); else LAUNCH16(12, false); break;
     case 16: if (track) LAUNCH16(16, true); else LAUNCH16(16, false); break;
     default: return hipErrorInvalidValue;
     }
