@@ -44,6 +44,10 @@ namespace mi355sw {
 #ifndef PK16_HALFTRACK
 #define PK16_HALFTRACK 1  // fast pass accumulates the chunk maximum on odd rows only (even rows: bound +5)
 #endif
+#ifndef PK16_SVC_A
+#define PK16_SVC_A 16     // step of a chunk at which the previous chunk's stores are published and the next inputs requested
+#define PK16_SVC_B 0      // second chance for the input prefetch (0: none)
+#endif
 #ifndef PK16_UNROLL
 #define PK16_UNROLL 4     // steps per loop body of the 64-step chunk loop
 #endif
@@ -83,6 +87,9 @@ __device__ __forceinline__ int2 ld_sys2_16(const int2* p) {
     unsigned long long x = __hip_atomic_load((const unsigned long long*) p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     return make_int2((int) (u32) x, (int) (u32) (x >> 32));
 }
+__device__ __forceinline__ int ld_u8_16(const unsigned char* p) {
+    return (int) __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 __device__ __forceinline__ void st_agent2_16(int2* p, int2 v) {
     unsigned long long x = ((unsigned long long) (u32) v.y << 32) | (u32) v.x;
     __hip_atomic_store((unsigned long long*) p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -95,6 +102,7 @@ struct __attribute__((aligned(16))) WaveLds16 {
     int2 out_tf[CHUNK];         // packed (T,F) words of the emit lane, one per step
     int2 dump[64];              // write-only slots of the non-emitting lanes (no EXEC toggling per step)
     int c1w[WIN + CHUNK + 8];   // per column j: mask(j) | mask(j-1)<<16
+    int c1s[WIN + CHUNK + 8];   // per column j: v_perm_b32 selector {code(j), zero, 4+code(j-1), zero} (table form)
     int red[3 * 64];
 };
 
@@ -103,12 +111,13 @@ struct Lane16 {
     s2 TL[R];       // T of the cell to the left      (lo: LO block row r, hi: HI block row r)
     s2 E[R];        // E of the cell to the left
     int M0[R];      // one-hot base masks of the two rows
+    int TLO[R], THI[R];   // table form of the same: byte c = score of the row against column code c (c < 4)
     s2 tup_prev;    // T of (row above the block, previous column)
     s2 tbot, fbot;  // bottoms produced at the previous step
     int best_t, best_r, best_j;   // best T (true, 32-bit), row index inside the lane (0..2R-1), column
 };
 
-template <int R, bool MASKED, bool TRACK, bool EMIT_ANY, bool HALF>
+template <int R, bool MASKED, bool TRACK, bool EMIT_ANY, bool HALF, bool PERM>
 __device__ __forceinline__ void wave_step16(Lane16<R>& st, WaveLds16* lds, const int u, const int lane,
                                             const int jl /* LO column of this lane at u=0 */, const int n,
                                             const int nvalid_lo, const int nvalid_hi, const int emit_lane,
@@ -117,7 +126,7 @@ __device__ __forceinline__ void wave_step16(Lane16<R>& st, WaveLds16* lds, const
     const int2 feed = feed_io;
     const int c1p = c1_io;
     feed_io = lds->in_tf[u + 1];
-    c1_io = lds->c1w[WIN + u + 1 - 2 * lane];
+    c1_io = PERM ? lds->c1s[WIN + u + 1 - 2 * lane] : lds->c1w[WIN + u + 1 - 2 * lane];
     // hand-off: LO <- previous lane's HI bottom (DPP), HI <- own LO bottom; lane 0 LO <- bus feed
     const int dT = wave_shr1_16(feed.x, as_i(st.tbot));
     const int dF = wave_shr1_16(feed.y, as_i(st.fbot));
@@ -141,8 +150,15 @@ __device__ __forceinline__ void wave_step16(Lane16<R>& st, WaveLds16* lds, const
     s2 Hbot = splat(0);
 #pragma unroll
     for (int r = 0; r < R; r++) {
-        const int x = st.M0[r] & c1p;
-        const us2 y = __builtin_elementwise_min(__builtin_bit_cast(us2, x), six);
+        // score + 5 of the two cells: one byte permute when every column in reach is one of <= 4 plain
+        // codes (table form), else one-hot AND + min
+        us2 y;
+        if (PERM) {
+            y = __builtin_bit_cast(us2, __builtin_amdgcn_perm((u32) st.THI[r], (u32) st.TLO[r], (u32) c1p));
+        } else {
+            const int x = st.M0[r] & c1p;
+            y = __builtin_elementwise_min(__builtin_bit_cast(us2, x), six);
+        }
         s2 Ev = padd_sat(pmax(st.TL[r], st.E[r]), m2);
         const s2 v = diag + __builtin_bit_cast(s2, y);
         const s2 g = pmax(pmax(v, Ev), Z[r]);              // off the row-to-row critical chain
@@ -231,17 +247,26 @@ __device__ __forceinline__ int chunk_max16(const s2 (&cm)[R]) {
 }
 
 // 64 systolic steps of one chunk (reads the staged inputs from LDS, leaves the emit row in out_tf)
-template <int R, bool MASKED, bool TRACKSTEP, bool EMIT_ANY, bool HALF>
+struct NoService16 { __device__ __forceinline__ void operator()(int) const {} };
+
+template <int R, bool MASKED, bool TRACKSTEP, bool EMIT_ANY, bool HALF, bool PERM, typename Svc>
 __device__ __forceinline__ void run_chunk16(Lane16<R>& st, WaveLds16* lds, const int lane, const int jl, const int n,
                                             const int nvalid_lo, const int nvalid_hi, const int emit_lane,
-                                            const int emit_row, const s2 (&Z)[R], const int bias, s2 (&cmax)[R]) {
+                                            const int emit_row, const s2 (&Z)[R], const int bias, s2 (&cmax)[R],
+                                            Svc&& service) {
     int2 feed = lds->in_tf[0];
-    int c1 = lds->c1w[WIN - 2 * lane];
+    int c1 = PERM ? lds->c1s[WIN - 2 * lane] : lds->c1w[WIN - 2 * lane];
     int2* out_base = (lane == emit_lane) ? &lds->out_tf[0] : &lds->dump[lane];
     const int out_stride = (lane == emit_lane) ? 1 : 0;
-#pragma unroll PK16_UNROLL
-    for (int u = 0; u < CHUNK; u++)
-        wave_step16<R, MASKED, TRACKSTEP, EMIT_ANY, HALF>(st, lds, u, lane, jl, n, nvalid_lo, nvalid_hi, emit_lane, emit_row, Z, bias, feed, c1, cmax, out_base, out_stride);
+#pragma unroll 1
+    for (int ub = 0; ub < CHUNK; ub += PK16_UNROLL) {
+        // in-chunk service points: wave-uniform branches at a loop-body boundary, where the schedule is cut anyway
+        if (ub == PK16_SVC_A) service(0);
+        if (PK16_SVC_B > 0 && ub == PK16_SVC_B) service(1);
+#pragma unroll
+        for (int k = 0; k < PK16_UNROLL; k++)
+            wave_step16<R, MASKED, TRACKSTEP, EMIT_ANY, HALF, PERM>(st, lds, ub + k, lane, jl, n, nvalid_lo, nvalid_hi, emit_lane, emit_row, Z, bias, feed, c1, cmax, out_base, out_stride);
+    }
 }
 
 template <int R, bool TRACK>
@@ -324,16 +349,19 @@ __device__ __attribute__((noinline)) void process_strip16(const KernelArgs* ap, 
     for (int r = 0; r < R; r++) Z[r] = splat(clamp16(2 * r - bias));
 #pragma unroll
     for (int r = 0; r < R; r++) {
-        int mk[2];
+        int mk[2], tb[2];
 #pragma unroll
         for (int half = 0; half < 2; half++) {
             const int g = (half ? lrow_hi : lrow_lo) + r;
             const int c0 = (g < a->m) ? (int) a->seq0[g] : a->pad_code;
             mk[half] = ((c0 < a->n_match_codes) ? (4 << c0) : 0) | 2;   // bit 1: the constant part of the score
+            tb[half] = 0x02020202 | ((c0 < a->n_match_codes && c0 < 4) ? (4 << (8 * c0)) : 0);
         }
         st.TL[r] = as_s2(pack(clamp16(h0[2 * r] - T_OFF - bias + 2 * r), clamp16(h0[2 * r + 1] - T_OFF - bias + 2 * r)));
         st.E[r] = as_s2(pack(clamp16(e0[2 * r] - bias + 2 * r), clamp16(e0[2 * r + 1] - bias + 2 * r)));
         st.M0[r] = pack(mk[0], mk[1]);
+        st.TLO[r] = tb[0];
+        st.THI[r] = tb[1];
     }
     {
         int hd[2];
@@ -355,6 +383,9 @@ __device__ __attribute__((noinline)) void process_strip16(const KernelArgs* ap, 
     // seq1 window starts empty
     lds->c1w[lane] = 0x00020002; lds->c1w[64 + lane] = 0x00020002; lds->c1w[128 + lane] = 0x00020002;
     if (lane < 8) lds->c1w[192 + lane] = 0x00020002;
+    lds->c1s[lane] = 0x0c040c00; lds->c1s[64 + lane] = 0x0c040c00; lds->c1s[128 + lane] = 0x0c040c00;
+    if (lane < 8) lds->c1s[192 + lane] = 0x0c040c00;
+    bool simple1 = false, simple2 = false;                // the previous two chunks held only plain codes (< 4)
 
     DBG16(1, 1);
     long long tr_start = 0, tr_first = 0; int tr_spins = 0;
@@ -363,6 +394,13 @@ __device__ __attribute__((noinline)) void process_strip16(const KernelArgs* ap, 
     // begin before they are published.  Run them at raised priority so that they proceed at single-wave
     // speed instead of a quarter of the SIMD (measured: hop 250 us -> ~50 us with 4 waves per SIMD).
     __builtin_amdgcn_s_setprio(3);
+    bool simple0 = false;
+    bool pf_valid = false;                                // next chunk's inputs are in pf_* (wave-uniform)
+    int2 pf_hf = make_int2(0, NEG_INF);
+    int pf_code = 255, pf_codep = 255;
+    int prog_async = 0;                                   // predecessor's progress, requested at the chunk start
+    int gb_async = TRACK ? __hip_atomic_load(a->gbest, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+    int flag_pending = -1;                                // progress value whose bus stores are still in flight
     for (int c = 0; c < nchunks; c++) {
         const int col0 = c * CHUNK;
         // graded: the younger the strip, the closer it is to the start-up front of the pipeline
@@ -373,37 +411,43 @@ __device__ __attribute__((noinline)) void process_strip16(const KernelArgs* ap, 
         const bool trc = (a->trace != nullptr) && (c == 1000 || c == 1);
         long long q0 = 0, q1 = 0, q2 = 0, q3 = 0, q4 = 0;
         if (trc) q0 = __builtin_amdgcn_s_memrealtime();
-        // (1) stage the input chunk
+        // (1) stage the input chunk: prefetched during the previous chunk when the predecessor was far enough
+        //     ahead (the usual case), otherwise wait for it here
         {
-            int need = col0 + CHUNK;
-            if (need > n) need = n;
-            if (col0 < n) {
-                int spins = 0;
-                while (poll_agent16(prog_in) < need && spins < (1 << 24)) {
-                    __builtin_amdgcn_s_sleep(2);
-                    spins++;
+            const int col = col0 + lane;
+            int2 hf = make_int2(0, NEG_INF);
+            int code = 255, codep = 255;
+            if (pf_valid) {
+                hf = pf_hf; code = pf_code; codep = pf_codep;
+            } else {
+                int need = col0 + CHUNK;
+                if (need > n) need = n;
+                if (col0 < n) {
+                    int spins = 0;
+                    while (poll_agent16(prog_in) < need && spins < (1 << 24)) {
+                        __builtin_amdgcn_s_sleep(2);
+                        spins++;
+                    }
+                    tr_spins += spins;
+                    if (spins >= (1 << 24) && lane == 0) atomicExch(a->error_flag, 1);
                 }
-                tr_spins += spins;
-
-                if (spins >= (1 << 24) && lane == 0) atomicExch(a->error_flag, 1);
+                if (col < n) {
+                    hf = ld_agent2_16(&a->bus[col]);
+                    code = ld_u8_16(&a->seq1[col]) >> 2;      // seq1 holds code*4 (shift form of the int32 kernel)
+                }
+                if (col >= 1 && col - 1 < n) codep = ld_u8_16(&a->seq1[col - 1]) >> 2;
             }
+            pf_valid = false;
             if (TRACK) {
                 // Seed: a cell below the best score already found anywhere can never be the answer, so every
                 // lane starts from the global running best (ties are still taken: the test below is >=).
                 // Without it each strip spends its first chunks in the exact path and the start-up delay of
-                // every hop of the strip pipeline triples.
-                gseen = poll_agent16(a->gbest);
+                // every hop of the strip pipeline triples.  The value was requested one chunk ago.
+                gseen = __builtin_amdgcn_readfirstlane(gb_async);
                 if (gseen > st.best_t) { st.best_t = gseen; st.best_r = 2 * R; st.best_j = -1; }
+                gb_async = __hip_atomic_load(a->gbest, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             if (trc) q1 = __builtin_amdgcn_s_memrealtime();
-            const int col = col0 + lane;
-            int2 hf = make_int2(0, NEG_INF);
-            int code = 255, codep = 255;
-            if (col < n) {
-                hf = ld_agent2_16(&a->bus[col]);
-                code = a->seq1[col] >> 2;               // seq1 holds code*4 (shift form of the int32 kernel)
-            }
-            if (col >= 1 && col - 1 < n) codep = a->seq1[col - 1] >> 2;
             const int mk = ((code < a->n_match_codes) ? (4 << code) : 0) | 2;
             const int mkp = ((codep < a->n_match_codes) ? (4 << codep) : 0) | 2;
             if (hf.x - T_OFF - bias > GUARD16) overflow = true;
@@ -413,10 +457,19 @@ __device__ __attribute__((noinline)) void process_strip16(const KernelArgs* ap, 
             lds->c1w[lane] = w0;
             lds->c1w[64 + lane] = w1;
             lds->c1w[128 + lane] = mk | (mkp << 16);
+            const int v0 = lds->c1s[64 + lane];
+            const int v1 = lds->c1s[128 + lane];
+            lds->c1s[lane] = v0;
+            lds->c1s[64 + lane] = v1;
+            lds->c1s[128 + lane] = (code & 3) | 0x0c000c00 | ((4 + (codep & 3)) << 16);
+            simple2 = simple1; simple1 = simple0;
+            simple0 = (col0 + CHUNK <= n) && !__any(code >= 4 || code >= a->n_match_codes);
             lds->in_tf[lane] = make_int2(clamp16(hf.x - T_OFF - bias - 2) << 16, clamp16(hf.y - bias - 2) << 16);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            // ask for the predecessor's progress now, look at the answer in the middle of the chunk
+            prog_async = __hip_atomic_load(prog_in, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         if (trc) q2 = __builtin_amdgcn_s_memrealtime();
         DBG16(3, 20);
@@ -440,10 +493,45 @@ __device__ __attribute__((noinline)) void process_strip16(const KernelArgs* ap, 
         constexpr int SLACK = HALF ? 5 : 0;                // what an untracked (even) row can exceed its neighbour by
         // The ragged last strip runs the ordinary code (rows past m are ordinary cells that never match);
         // only when its DP row m-1 is wanted (last row) does the emit position have to move off the bottom.
-        if (emit_any && masked) run_chunk16<R, true, false, true, HALF>(st, lds, lane, jl, n, nvalid_lo, nvalid_hi, emit_lane, emit_row, Z, bias, cmax);
-        else if (emit_any) run_chunk16<R, false, false, true, HALF>(st, lds, lane, jl, n, nvalid_lo, nvalid_hi, emit_lane, emit_row, Z, bias, cmax);
-        else if (masked) run_chunk16<R, true, false, false, HALF>(st, lds, lane, jl, n, nvalid_lo, nvalid_hi, 63, R - 1, Z, bias, cmax);
-        else run_chunk16<R, false, false, false, HALF>(st, lds, lane, jl, n, nvalid_lo, nvalid_hi, 63, R - 1, Z, bias, cmax);
+        // ---- mid-chunk service: everything that needs a memory round trip happens here, half a chunk after
+        //      it was requested, so that no latency is exposed at the chunk boundary ----
+        auto service = [&](const int second) {
+            // (a) the previous chunk's bus stores have landed by now: publish them
+            if (!second) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (flag_pending >= 0) {
+                    if (lane == 0) st_agent16(prog_out, flag_pending);
+                    flag_pending = -1;
+                }
+            }
+            // (b) is the next input chunk already there?  Then fetch it now (the loads are issued after the
+            //     progress value was observed, so they see the published data); otherwise ask again for the
+            //     second service point
+            const int ncol0 = col0 + CHUNK;
+            if (c + 1 < nchunks && !pf_valid) {
+                int need = ncol0 + CHUNK;
+                if (need > n) need = n;
+                const int avail = __builtin_amdgcn_readfirstlane(prog_async);
+                if (ncol0 >= n || avail >= need) {
+                    const int col = ncol0 + lane;
+                    pf_hf = make_int2(0, NEG_INF); pf_code = 255; pf_codep = 255;
+                    if (col < n) {
+                        pf_hf = ld_agent2_16(&a->bus[col]);
+                        pf_code = ld_u8_16(&a->seq1[col]) >> 2;
+                    }
+                    if (col >= 1 && col - 1 < n) pf_codep = ld_u8_16(&a->seq1[col - 1]) >> 2;
+                    pf_valid = true;
+                } else if (!second) {
+                    prog_async = __hip_atomic_load(prog_in, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        };
+        const bool use_perm = !masked && !emit_any && simple0 && simple1 && simple2;
+        if (use_perm) run_chunk16<R, false, false, false, HALF, true>(st, lds, lane, jl, n, nvalid_lo, nvalid_hi, 63, R - 1, Z, bias, cmax, service);
+        else if (emit_any && masked) run_chunk16<R, true, false, true, HALF, false>(st, lds, lane, jl, n, nvalid_lo, nvalid_hi, emit_lane, emit_row, Z, bias, cmax, service);
+        else if (emit_any) run_chunk16<R, false, false, true, HALF, false>(st, lds, lane, jl, n, nvalid_lo, nvalid_hi, emit_lane, emit_row, Z, bias, cmax, service);
+        else if (masked) run_chunk16<R, true, false, false, HALF, false>(st, lds, lane, jl, n, nvalid_lo, nvalid_hi, 63, R - 1, Z, bias, cmax, service);
+        else run_chunk16<R, false, false, false, HALF, false>(st, lds, lane, jl, n, nvalid_lo, nvalid_hi, 63, R - 1, Z, bias, cmax, service);
         if (TRACK) {
             if (__any(chunk_max16<R, HALF>(cmax) + SLACK + bias >= st.best_t)) {
 #pragma unroll
@@ -452,8 +540,8 @@ __device__ __attribute__((noinline)) void process_strip16(const KernelArgs* ap, 
                 s2 cmax2[R];
 #pragma unroll
                 for (int r = 0; r < R; r++) cmax2[r] = splat(-32768);
-                if (emit_any) run_chunk16<R, true, true, true, false>(st, lds, lane, jl, n, nvalid_lo, nvalid_hi, emit_lane, emit_row, Z, bias, cmax2);
-                else run_chunk16<R, true, true, false, false>(st, lds, lane, jl, n, nvalid_lo, nvalid_hi, 63, R - 1, Z, bias, cmax2);
+                if (emit_any) run_chunk16<R, true, true, true, false, false>(st, lds, lane, jl, n, nvalid_lo, nvalid_hi, emit_lane, emit_row, Z, bias, cmax2, NoService16());
+                else run_chunk16<R, true, true, false, false, false>(st, lds, lane, jl, n, nvalid_lo, nvalid_hi, 63, R - 1, Z, bias, cmax2, NoService16());
             }
         }
         if (trc) q3 = __builtin_amdgcn_s_memrealtime();
@@ -463,20 +551,26 @@ __device__ __attribute__((noinline)) void process_strip16(const KernelArgs* ap, 
             const int cmv = chunk_max16<R, HALF>(cmax);    // exact, or a lower bound within SLACK of it
             if (cmv + SLACK > GUARD16) overflow = true;
             lane_max = max(lane_max, cmv + bias);
-            int w = cmv;
+            // the wave-wide maximum (six cross-lane steps) is only needed when one of its three consumers
+            // can fire; three ballots decide that
+            const bool need_wmax = __any(cmv + SLACK > REBASE_HI) || (TRACK && __any(cmv + bias > gseen)) ||
+                                   (bias > 0 && !__any(cmv >= 0));
+            if (need_wmax) {
+                int w = cmv;
 #pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) w = max(w, __shfl_xor(w, d));
-            const int wmax = __builtin_amdgcn_readfirstlane(w);
-            if (TRACK && wmax + bias > gseen) {
-                if (lane == 0) atomicMax(a->gbest, wmax + bias);
-            }
-            int nb = bias;
-            if (wmax + SLACK > REBASE_HI) nb = bias + (wmax - REBASE_TO);
-            else if (wmax < 0 && bias > 0 && wmax > -32768) nb = max(0, bias + max(wmax - REBASE_TO, -30000));
-            if (nb != bias) {
-                // shift every live 16-bit value by the same amount (saturating: the -INF image stays put
-                // when the window moves up); outputs of this chunk were produced with the old bias
-                rebias_to = nb;
+                for (int d = 32; d >= 1; d >>= 1) w = max(w, __shfl_xor(w, d));
+                const int wmax = __builtin_amdgcn_readfirstlane(w);
+                if (TRACK && wmax + bias > gseen) {
+                    if (lane == 0) atomicMax(a->gbest, wmax + bias);
+                }
+                int nb = bias;
+                if (wmax + SLACK > REBASE_HI) nb = bias + (wmax - REBASE_TO);
+                else if (wmax < 0 && bias > 0 && wmax > -32768) nb = max(0, bias + max(wmax - REBASE_TO, -30000));
+                if (nb != bias) {
+                    // shift every live 16-bit value by the same amount (saturating: the -INF image stays put
+                    // when the window moves up); outputs of this chunk were produced with the old bias
+                    rebias_to = nb;
+                }
             }
         }
         // (3) output chunk: columns col0-emit_v .. col0-emit_v+63
@@ -497,11 +591,12 @@ __device__ __attribute__((noinline)) void process_strip16(const KernelArgs* ap, 
                 if (lastrow != nullptr) lastrow[col] = hf;
                 if (ckpt != nullptr) ckpt[col] = hf;
             }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // the progress flag follows at the next mid-chunk service (or after the last chunk), when the
+            // stores have drained without anybody waiting for them
             int done = col0 - emit_v + CHUNK;
             if (done > n) done = n;
             if (done < 0) done = 0;
-            if (lane == 0) st_agent16(prog_out, done);
+            flag_pending = done;
         }
         if (rebias_to != bias) {
             const s2 dlt = splat(rebias_to - bias);
@@ -525,6 +620,8 @@ __device__ __attribute__((noinline)) void process_strip16(const KernelArgs* ap, 
         }
     }
 
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (flag_pending >= 0 && lane == 0) st_agent16(prog_out, flag_pending);
     __builtin_amdgcn_s_setprio(0);
     if (__any(overflow)) {
         if (lane == 0) { atomicExch(a->error_flag, 16); st_agent16(a->abort_flag, 1); }
