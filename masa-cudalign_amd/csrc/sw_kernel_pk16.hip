@@ -395,6 +395,7 @@ __device__ __attribute__((noinline)) void process_strip16(const KernelArgs* ap, 
     // speed instead of a quarter of the SIMD (measured: hop 250 us -> ~50 us with 4 waves per SIMD).
     __builtin_amdgcn_s_setprio(3);
     bool simple0 = false;
+    bool exact_mode = false;                              // wave-uniform: run the exact-tracking code without a fast pass first
     bool pf_valid = false;                                // next chunk's inputs are in pf_* (wave-uniform)
     int2 pf_hf = make_int2(0, NEG_INF);
     int pf_code = 255, pf_codep = 255;
@@ -483,8 +484,11 @@ __device__ __attribute__((noinline)) void process_strip16(const KernelArgs* ap, 
         // Fast pass: no position bookkeeping at all.  Only if some lane's chunk maximum reaches its
         // (globally seeded) threshold is the chunk replayed from a register snapshot with the exact
         // per-step bookkeeping -- a rare event once the running best is above the background level.
+        // While chunks keep producing new candidates (start of the run, a ridge of a real alignment) the
+        // fast pass would be thrown away every time: such stretches run the exact code directly
+        // (exact_mode), one pass per chunk, and return to the fast pass after a chunk without any update.
         Lane16<R> snap;
-        if (TRACK) {
+        if (TRACK && !exact_mode) {
 #pragma unroll
             for (int r = 0; r < R; r++) { snap.TL[r] = st.TL[r]; snap.E[r] = st.E[r]; }
             snap.tup_prev = st.tup_prev; snap.tbot = st.tbot; snap.fbot = st.fbot;
@@ -527,6 +531,12 @@ __device__ __attribute__((noinline)) void process_strip16(const KernelArgs* ap, 
             }
         };
         const bool use_perm = !masked && !emit_any && simple0 && simple1 && simple2;
+        if (TRACK && exact_mode) {
+            const int bt0 = st.best_t, bj0 = st.best_j, br0 = st.best_r;
+            if (emit_any) run_chunk16<R, true, true, true, false, false>(st, lds, lane, jl, n, nvalid_lo, nvalid_hi, emit_lane, emit_row, Z, bias, cmax, service);
+            else run_chunk16<R, true, true, false, false, false>(st, lds, lane, jl, n, nvalid_lo, nvalid_hi, 63, R - 1, Z, bias, cmax, service);
+            exact_mode = __any(st.best_t != bt0 || st.best_j != bj0 || st.best_r != br0);
+        } else {
         if (use_perm) run_chunk16<R, false, false, false, HALF, true>(st, lds, lane, jl, n, nvalid_lo, nvalid_hi, 63, R - 1, Z, bias, cmax, service);
         else if (emit_any && masked) run_chunk16<R, true, false, true, HALF, false>(st, lds, lane, jl, n, nvalid_lo, nvalid_hi, emit_lane, emit_row, Z, bias, cmax, service);
         else if (emit_any) run_chunk16<R, false, false, true, HALF, false>(st, lds, lane, jl, n, nvalid_lo, nvalid_hi, emit_lane, emit_row, Z, bias, cmax, service);
@@ -542,7 +552,9 @@ __device__ __attribute__((noinline)) void process_strip16(const KernelArgs* ap, 
                 for (int r = 0; r < R; r++) cmax2[r] = splat(-32768);
                 if (emit_any) run_chunk16<R, true, true, true, false, false>(st, lds, lane, jl, n, nvalid_lo, nvalid_hi, emit_lane, emit_row, Z, bias, cmax2, NoService16());
                 else run_chunk16<R, true, true, false, false, false>(st, lds, lane, jl, n, nvalid_lo, nvalid_hi, 63, R - 1, Z, bias, cmax2, NoService16());
+                exact_mode = true;
             }
+        }
         }
         if (trc) q3 = __builtin_amdgcn_s_memrealtime();
         DBG16(3, 30);
@@ -616,7 +628,11 @@ __device__ __attribute__((noinline)) void process_strip16(const KernelArgs* ap, 
             q4 = __builtin_amdgcn_s_memrealtime();
             long long* tr = a->trace + 4 * s;
             const long long v = ((q1 - q0) & 0xffff) | (((q2 - q1) & 0xffff) << 16) | (((q3 - q2) & 0xffff) << 32) | (((q4 - q3) & 0xffff) << 48);
+#ifdef PK16_TRACE_ABS   // absolute times (after the input wait) of chunk 1 and chunk 1000 instead of the phase split
+            if (c == 1) tr[2] = q1; else tr[3] = q1;
+#else
             if (c == 1) tr[2] = v; else tr[3] = v;
+#endif
         }
     }
 

@@ -38,7 +38,7 @@ def test_golden_fixture(case, pkg, aligner):
             assert digest(mg.specialRow(i)) == case["special_rows"][str(i)], "special row %d" % i
 
 
-@pytest.mark.parametrize("R", [4, 8, 16])
+@pytest.mark.parametrize("R", [4, 8, 12, 16, 24, 32])
 @pytest.mark.parametrize("m,n", [(1, 1), (1, 300), (300, 1), (63, 64), (64, 63), (255, 129), (256, 128), (257, 127),
                                  (513, 65), (1025, 1023), (2048, 100), (5000, 4321)])
 def test_all_borders_vs_oracle_sw(pkg, oracle, R, m, n):
@@ -235,3 +235,71 @@ def test_two_phase_exact_position(pkg, oracle, monkeypatch):
             assert tuple(mg.getBestScore()) == tuple(oracle.stage1(s0, s1)["best"])
         finally:
             al.close()
+
+
+@pytest.mark.parametrize("R", [8, 24])
+def test_score_lookup_paths_switch_inside_a_strip(pkg, oracle, R):
+    """The packed kernel scores a chunk with a byte permute when every column in reach is one of <= 4 plain
+    letters and with the one-hot AND/min form otherwise.  Runs of N (a 5th letter common to both sequences, so
+    N==N matches as in the reference's byte compare), isolated foreign bytes and long clean stretches make
+    the wavefront switch back and forth; best cell, last row, last column and special rows stay bit-exact."""
+    m, n = 3000, 6000
+    s0, s1 = pkg.seqgen.related_pair(m, n, cfg=1234)
+    s0, s1 = s0.copy(), s1.copy()
+    s1[700:760] = ord("N"); s1[2000] = ord("N"); s1[2300:2310] = ord("R"); s1[4100:4400:7] = ord("N")
+    s0[100:180] = ord("N"); s0[1500] = ord("Y"); s0[2500:2520] = ord("N")
+    al = pkg.MI355Aligner(device=0, rows_per_lane=R)
+    try:
+        al.setSequences(s0, s1)
+        part = pkg.Partition(0, 0, m, n)
+        mg = pkg.Stage1Manager(part, keep_last_row=True, keep_last_column=True)
+        al.alignPartition(part, mg)
+        assert al.getStatistics()["profile_kernel"] == 2
+        ref = oracle.stage1(s0, s1, want_last_row=True, want_last_col=True)
+        assert tuple(mg.getBestScore()) == tuple(ref["best"])
+        assert np.array_equal(mg.lastRow(), ref["last_row"])
+        assert np.array_equal(mg.lastColumn(), ref["last_col"])
+    finally:
+        al.close()
+
+
+def test_three_letter_alphabet_uses_table_form(pkg, oracle):
+    """fewer than four common letters, and letters that occur in one sequence only (never match)."""
+    rng = np.random.default_rng(5)
+    s0 = rng.choice(np.frombuffer(b"ACGX", dtype=np.uint8), size=2500)
+    s1 = rng.choice(np.frombuffer(b"ACGQ", dtype=np.uint8), size=5000)
+    s1[1000:1400] = s0[300:700]
+    al = pkg.MI355Aligner(device=0)
+    try:
+        al.setSequences(s0, s1)
+        part = pkg.Partition(0, 0, len(s0), len(s1))
+        mg = pkg.Stage1Manager(part, keep_last_row=True, keep_last_column=True)
+        al.alignPartition(part, mg)
+        ref = oracle.stage1(s0, s1, want_last_row=True, want_last_col=True)
+        assert tuple(mg.getBestScore()) == tuple(ref["best"])
+        assert np.array_equal(mg.lastRow(), ref["last_row"])
+        assert np.array_equal(mg.lastColumn(), ref["last_col"])
+    finally:
+        al.close()
+
+
+def test_special_rows_with_1536_row_strips(pkg, oracle):
+    """strip heights that do not divide 8192: special rows sit at multiples of ceil(8192/1536)*1536 = 9216
+    rows (AbstractDiagonalAligner::isSpecialRow with MINIMUM_FLUSH_INTERVAL), and hold the oracle's values."""
+    m, n = 30000, 4000
+    s0, s1 = pkg.seqgen.related_pair(m, n, cfg=77)
+    al = pkg.MI355Aligner(device=0, rows_per_lane=24)
+    try:
+        al.setSequences(s0, s1)
+        part = pkg.Partition(0, 0, m, n)
+        mg = pkg.Stage1Manager(part, special_row_interval=1000, keep_last_row=True)
+        al.alignPartition(part, mg)
+        rows = sorted(mg.special_rows)
+        assert [r for r in rows if r < m] == [9216, 18432, 27648]
+        ref = oracle.stage1(s0, s1, block_h=9216, block_w=n, special_row_interval=9216, want_last_row=True)
+        assert tuple(mg.getBestScore()) == tuple(ref["best"])
+        want = dict(zip(ref["special_row_ids"], ref["special_rows"]))
+        for i in (9216, 18432, 27648):
+            assert np.array_equal(mg.specialRow(i), want[i]), i
+    finally:
+        al.close()
