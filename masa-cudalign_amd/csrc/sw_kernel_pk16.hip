@@ -48,8 +48,11 @@ namespace mi355sw {
 #define PK16_SVC_A 16     // step of a chunk at which the previous chunk's stores are published and the next inputs requested
 #define PK16_SVC_B 0      // second chance for the input prefetch (0: none)
 #endif
+#ifndef PK16_EXACT_MODE
+#define PK16_EXACT_MODE 1  // after a replayed chunk, run the following chunks in the exact code directly
+#endif
 #ifndef PK16_UNROLL
-#define PK16_UNROLL 4     // steps per loop body of the 64-step chunk loop
+#define PK16_UNROLL 8     // steps per loop body of the 64-step chunk loop (measured: 8 beats 2 and 4 by 2-4 %)
 #endif
 #define GUARD16 30000      // chunk maximum above this => overflow report (wrap needs 32767)
 
@@ -122,7 +125,7 @@ __device__ __forceinline__ void wave_step16(Lane16<R>& st, WaveLds16* lds, const
                                             const int jl /* LO column of this lane at u=0 */, const int n,
                                             const int nvalid_lo, const int nvalid_hi, const int emit_lane,
                                             const int emit_row, const s2 (&Z)[R], const int bias, int2& feed_io, int& c1_io,
-                                            s2 (&cm)[R], int2* out_base, const int out_stride) {
+                                            s2 (&cm)[R], int2* out_base, const int out_stride, const bool all_rows_valid) {
     const int2 feed = feed_io;
     const int c1p = c1_io;
     feed_io = lds->in_tf[u + 1];
@@ -215,6 +218,32 @@ __device__ __forceinline__ void wave_step16(Lane16<R>& st, WaveLds16* lds, const
         const int m = max(lo16(mi), hi16(mi)) + bias;
         if (__any(m >= st.best_t)) {
             const int j = jl + u;
+            if (all_rows_valid) {
+                // Only the step's best cell of the lane can displace the running best: the larger half
+                // maximum (LO on a tie: smaller row), at the FIRST row that reaches it.  Packed search for
+                // that row: (ms - tt) is 0 exactly there.
+                us2 fr = {0x7fff, 0x7fff};
+                const us2 one = {1, 1}, big = {0x4000, 0x4000};
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    const s2 tt = newT[r] + splat(-2 * r);
+                    const us2 d = __builtin_bit_cast(us2, ms - tt);
+                    const us2 z = __builtin_elementwise_min(d, one);
+                    const us2 rv = {(unsigned short) r, (unsigned short) r};
+                    fr = __builtin_elementwise_min(fr, (us2) (z * big + rv));
+                }
+                const int fi = __builtin_bit_cast(int, fr);
+                const int mlo = lo16(mi), mhi = hi16(mi);
+                const bool vlo = MASKED ? ((vmask & 1) != 0) : true;
+                const bool vhi = MASKED ? (((vmask >> 16) & 1) != 0) : true;
+                const bool use_hi = vhi && (!vlo || mhi > mlo);
+                const int t = (use_hi ? mhi : mlo) + bias;
+                const int rr = use_hi ? (R + (int) ((u32) fi >> 16)) : (fi & 0xffff);
+                const bool upd = (use_hi ? vhi : vlo) && ((t > st.best_t) || (t == st.best_t && rr < st.best_r));
+                st.best_t = upd ? t : st.best_t;
+                st.best_r = upd ? rr : st.best_r;
+                st.best_j = upd ? (j - (use_hi ? 1 : 0)) : st.best_j;
+            } else
 #pragma unroll
             for (int half = 0; half < 2; half++) {
                 const int nv = half ? nvalid_hi : nvalid_lo;
@@ -253,7 +282,7 @@ template <int R, bool MASKED, bool TRACKSTEP, bool EMIT_ANY, bool HALF, bool PER
 __device__ __forceinline__ void run_chunk16(Lane16<R>& st, WaveLds16* lds, const int lane, const int jl, const int n,
                                             const int nvalid_lo, const int nvalid_hi, const int emit_lane,
                                             const int emit_row, const s2 (&Z)[R], const int bias, s2 (&cmax)[R],
-                                            Svc&& service) {
+                                            Svc&& service, const bool all_rows_valid = true) {
     int2 feed = lds->in_tf[0];
     int c1 = PERM ? lds->c1s[WIN - 2 * lane] : lds->c1w[WIN - 2 * lane];
     int2* out_base = (lane == emit_lane) ? &lds->out_tf[0] : &lds->dump[lane];
@@ -265,7 +294,7 @@ __device__ __forceinline__ void run_chunk16(Lane16<R>& st, WaveLds16* lds, const
         if (PK16_SVC_B > 0 && ub == PK16_SVC_B) service(1);
 #pragma unroll
         for (int k = 0; k < PK16_UNROLL; k++)
-            wave_step16<R, MASKED, TRACKSTEP, EMIT_ANY, HALF, PERM>(st, lds, ub + k, lane, jl, n, nvalid_lo, nvalid_hi, emit_lane, emit_row, Z, bias, feed, c1, cmax, out_base, out_stride);
+            wave_step16<R, MASKED, TRACKSTEP, EMIT_ANY, HALF, PERM>(st, lds, ub + k, lane, jl, n, nvalid_lo, nvalid_hi, emit_lane, emit_row, Z, bias, feed, c1, cmax, out_base, out_stride, all_rows_valid);
     }
 }
 
@@ -533,8 +562,9 @@ __device__ __attribute__((noinline)) void process_strip16(const KernelArgs* ap, 
         const bool use_perm = !masked && !emit_any && simple0 && simple1 && simple2;
         if (TRACK && exact_mode) {
             const int bt0 = st.best_t, bj0 = st.best_j, br0 = st.best_r;
-            if (emit_any) run_chunk16<R, true, true, true, false, false>(st, lds, lane, jl, n, nvalid_lo, nvalid_hi, emit_lane, emit_row, Z, bias, cmax, service);
-            else run_chunk16<R, true, true, false, false, false>(st, lds, lane, jl, n, nvalid_lo, nvalid_hi, 63, R - 1, Z, bias, cmax, service);
+            if (emit_any) run_chunk16<R, true, true, true, false, false>(st, lds, lane, jl, n, nvalid_lo, nvalid_hi, emit_lane, emit_row, Z, bias, cmax, service, !ragged);
+            else if (masked) run_chunk16<R, true, true, false, false, false>(st, lds, lane, jl, n, nvalid_lo, nvalid_hi, 63, R - 1, Z, bias, cmax, service, !ragged);
+            else run_chunk16<R, false, true, false, false, false>(st, lds, lane, jl, n, nvalid_lo, nvalid_hi, 63, R - 1, Z, bias, cmax, service, !ragged);
             exact_mode = __any(st.best_t != bt0 || st.best_j != bj0 || st.best_r != br0);
         } else {
         if (use_perm) run_chunk16<R, false, false, false, HALF, true>(st, lds, lane, jl, n, nvalid_lo, nvalid_hi, 63, R - 1, Z, bias, cmax, service);
@@ -550,9 +580,10 @@ __device__ __attribute__((noinline)) void process_strip16(const KernelArgs* ap, 
                 s2 cmax2[R];
 #pragma unroll
                 for (int r = 0; r < R; r++) cmax2[r] = splat(-32768);
-                if (emit_any) run_chunk16<R, true, true, true, false, false>(st, lds, lane, jl, n, nvalid_lo, nvalid_hi, emit_lane, emit_row, Z, bias, cmax2, NoService16());
-                else run_chunk16<R, true, true, false, false, false>(st, lds, lane, jl, n, nvalid_lo, nvalid_hi, 63, R - 1, Z, bias, cmax2, NoService16());
-                exact_mode = true;
+                if (emit_any) run_chunk16<R, true, true, true, false, false>(st, lds, lane, jl, n, nvalid_lo, nvalid_hi, emit_lane, emit_row, Z, bias, cmax2, NoService16(), !ragged);
+                else if (masked) run_chunk16<R, true, true, false, false, false>(st, lds, lane, jl, n, nvalid_lo, nvalid_hi, 63, R - 1, Z, bias, cmax2, NoService16(), !ragged);
+                else run_chunk16<R, false, true, false, false, false>(st, lds, lane, jl, n, nvalid_lo, nvalid_hi, 63, R - 1, Z, bias, cmax2, NoService16(), !ragged);
+                exact_mode = (PK16_EXACT_MODE != 0);
             }
         }
         }
