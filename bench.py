@@ -28,12 +28,15 @@ HBM_PEAK_GBS = 8000.0                 # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # VALU issue measured on this chip (tools/micro_valu.hip): one wave64 instruction (int32 or packed 2x16)
 # per 4 cycles per SIMD, i.e. 0.59 wave-instructions/ns/SIMD at the 2.38 GHz the chip holds under this load
 VALU_PEAK_WAVE_INSTR = 256 * 4 * 0.59e9
-# VALU instructions per wave-step (SQ_INSTS_VALU / steps; one step = strip_rows cells)
 # HBM-side traffic of one launch from the PMC passes (profiles/r01_pk16_hbm_pmc.json: FETCH_SIZE x2 gfx950
 # correction + WRITE_SIZE), keyed by (kernel, m, n, strip_rows); other configurations report null
-PMC_TRAFFIC_BYTES = {("pk16", 3000000, 3000000, 1024): 170680920384.0}
+PMC_TRAFFIC_BYTES = {("pk16", 3000000, 3000000, 1536): 112971067776.0}
+# VALU instructions per wave-step (SQ_INSTS_VALU / wave-steps; one step = strip_rows cells).  pk16/1536 is
+# measured (profiles/r01_pk16_sq_pmc.json: 127.8); the other packed heights scale its 9.65 per packed row
+# pair + 12 per step; int32 figures are from profiles/r01_int32_sq_pmc.json
 VALU_PER_STEP = {("int32", 256): 47.0, ("int32", 512): 86.3, ("int32", 1024): 165.0,
-                 ("pk16", 256): 35.0, ("pk16", 512): 59.0, ("pk16", 1024): 105.8, ("pk16", 2048): 200.0}
+                 ("pk16", 256): 31.3, ("pk16", 512): 50.6, ("pk16", 768): 69.9, ("pk16", 1024): 89.2,
+                 ("pk16", 1536): 127.8, ("pk16", 2048): 166.4}
 
 
 def cpu_baseline(pkg, seconds_budget=20.0):
@@ -112,10 +115,16 @@ def main():
     s0, s1 = pkg.seqgen.unrelated_pair(m, n, cfg=2)
     waves = args.waves
     if waves == 0 and world > 1 and comm == "nccl":
-        waves = 256 * 12            # leave VGPR room on every SIMD for RCCL's send/recv kernels
-    al = pkg.MI355Aligner(device=local_rank, rows_per_lane=args.rows_per_lane, waves=waves)
-    al.setSequences(s0, s1)            # H2D once, outside the timed region
+        # every strip wavefront owns a whole SIMD; RCCL's send/recv kernels need SIMDs of
+        # their own, so leave 32 CUs' worth unclaimed (experimental transport -- "host" is the default)
+        waves = (256 - 32) * 4
     lim = band_limits(n, [1] * world)
+    rows_per_lane = args.rows_per_lane
+    if rows_per_lane == 0 and world > 1:
+        from masa_cudalign_amd.bands import rows_per_lane_for_bands
+        rows_per_lane = rows_per_lane_for_bands(m, lim[1] - lim[0], world, waves or 1024)
+    al = pkg.MI355Aligner(device=local_rank, rows_per_lane=rows_per_lane, waves=waves)
+    al.setSequences(s0, s1)            # H2D once, outside the timed region
     j0, j1 = lim[rank], lim[rank + 1]
 
     class _Dist:                       # boundary-column transport: RCCL p2p (device tensors) or gloo (host)
@@ -204,7 +213,7 @@ def main():
 
 def _valu(st, band_cells, k_ms):
     kind = "pk16" if st["profile_kernel"] == 2 else "int32"
-    per_step = VALU_PER_STEP.get((kind, st["strip_rows"]), 86.3)
+    per_step = VALU_PER_STEP.get((kind, st["strip_rows"]), 0.0832 * st["strip_rows"])
     achieved = band_cells / st["strip_rows"] * per_step / (k_ms * 1e-3)
     return {"valu_instr_per_step": per_step, "cells_per_step": st["strip_rows"], "achieved_wave_instr_per_s": achieved,
             "peak_wave_instr_per_s": VALU_PEAK_WAVE_INSTR, "frac": achieved / VALU_PEAK_WAVE_INSTR}

@@ -30,6 +30,23 @@ def band_limits(n, weights):
     return [(n * acc[g]) // tot for g in range(len(weights) + 1)]
 
 
+def rows_per_lane_for_bands(m, band_cols, world, waves=1024):
+    """Strip height for a chain of `world` column bands.  Band g+1 can only start once band g has swept
+    its first strips across the whole band, so the chain's start-up costs (world-1) * band_cols steps on
+    top of one band's own work; the step time grows with the strip height (runtime.cpp: 70 + 11.8*R ns)
+    while taller strips do the work itself faster.  Same cost model as the library's single-band planner
+    plus that start-up term."""
+    best, tb = 0, None
+    for R in (4, 8, 12, 16, 24, 32):
+        step = 70.0 + 11.8 * R
+        strips = -(-m // (64 * R))
+        rounds = -(-strips // waves)
+        t = step * (rounds * band_cols + 280.0 * min(strips, waves) + (world - 1) * band_cols)
+        if tb is None or t < tb:
+            best, tb = R, t
+    return best
+
+
 def canonical_best(cands):
     """BestScoreList order (M/common/BestScoreList.hpp:30-38): score desc, i asc, j asc."""
     best = (-1, -1, -INF)
