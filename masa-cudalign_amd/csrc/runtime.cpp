@@ -331,7 +331,7 @@ int mi355sw_stream_begin(mi355sw_handle* h, const mi355sw_partition* part, const
     const int m = part->i1 - part->i0, n = part->j1 - part->j0;
     h->m = m; h->n = n;
     {
-        const bool will16 = (p->recurrence_type == MI355SW_SMITH_WATERMAN) && h->profile && !p->force_int32 &&
+        const bool will16 = h->profile && !p->force_int32 &&
                             !(h->cfg.flags & MI355SW_F_FORCE_INT32);
         h->R = pick_rows_per_lane(h, m, n, will16);
         // the int32 kernels are instantiated for R in {4,8,16}
@@ -357,7 +357,7 @@ int mi355sw_stream_begin(mi355sw_handle* h, const mi355sw_partition* part, const
         h->n_special = (int) (((long long) m - 1) / ((long long) K * h->SH));   // rows K*SH*k < m
     }
     h->special_pitch = ((long long) n + 63) / 64 * 64;
-    h->use16 = (p->recurrence_type == MI355SW_SMITH_WATERMAN) && h->profile && !p->force_int32 &&
+    h->use16 = h->profile && !p->force_int32 &&
                !(h->cfg.flags & MI355SW_F_FORCE_INT32);
     // Two-phase best: the main pass keeps only each strip's best VALUE (no per-step position test, no
     // rare path on the start-up critical path of every strip); the canonical cell is then recomputed
@@ -509,7 +509,7 @@ int mi355sw_stream_begin(mi355sw_handle* h, const mi355sw_partition* part, const
     if (h->use16) {
         h->stats.profile_kernel = 2;
         HIPCHK(h, launch_strip_kernel_pk16(a, (KernelArgs*) h->d_kargs.p, h->R / 2, waves, h->stream,
-                                           p->track_best != 0 && !h->two_phase));
+                                           p->track_best != 0 && !h->two_phase, p->recurrence_type == MI355SW_SMITH_WATERMAN));
     } else {
         HIPCHK(h, launch_strip_kernel(a, (KernelArgs*) h->d_kargs.p, h->R, waves, h->stream, p->recurrence_type == MI355SW_SMITH_WATERMAN,
                                       h->profile, p->track_best != 0));
@@ -654,7 +654,8 @@ static int run_exact_pass(mi355sw_handle* h, int s_star, int want_score, mi355sw
     HIPCHK(h, hipEventCreate(&e0));
     HIPCHK(h, hipEventCreate(&e1));
     HIPCHK(h, hipEventRecord(e0, h->stream));
-    HIPCHK(h, launch_strip_kernel_pk16(b, (KernelArgs*) h->d_kargs.p, h->R / 2, waves, h->stream, true));
+    HIPCHK(h, launch_strip_kernel_pk16(b, (KernelArgs*) h->d_kargs.p, h->R / 2, waves, h->stream, true,
+                                       h->sp.recurrence_type == MI355SW_SMITH_WATERMAN));
     HIPCHK(h, hipEventRecord(e1, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     float ms = 0.f;

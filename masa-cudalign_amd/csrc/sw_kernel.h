@@ -65,7 +65,7 @@ __device__ __forceinline__ UniformArgs uniform_args(const KernelArgs* p) {
 hipError_t launch_strip_kernel(const KernelArgs& a, KernelArgs* dargs, int rows_per_lane, int grid, hipStream_t stream,
                                bool sw, bool profile, bool track);
 // packed 16-bit SW kernel (sw_kernel_pk16.hip): strip height = 128*rows_per_half
-hipError_t launch_strip_kernel_pk16(const KernelArgs& a, KernelArgs* dargs, int rows_per_half, int grid, hipStream_t stream, bool track);
+hipError_t launch_strip_kernel_pk16(const KernelArgs& a, KernelArgs* dargs, int rows_per_half, int grid, hipStream_t stream, bool track, bool sw);
 hipError_t launch_fill_bus(int2* bus, int n, int init_type, int start_offset, hipStream_t stream);
 hipError_t launch_fill_int(int* p, long long count, int value, hipStream_t stream);
 

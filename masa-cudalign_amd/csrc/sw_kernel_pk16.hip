@@ -41,6 +41,7 @@ namespace mi355sw {
 #define PRIO_CHUNKS 4       // chunks of every strip that run at raised wave priority
 #define REBASE_HI 20000     // chunk maximum (relative) above which the window is moved up ...
 #define REBASE_TO 8000      // ... so that the maximum sits here
+#define REBASE_LO (-8000)   // NW only: chunk maximum below which the window is moved down
 #ifndef PK16_HALFTRACK
 #define PK16_HALFTRACK 1  // fast pass accumulates the chunk maximum on odd rows only (even rows: bound +5)
 #endif
@@ -120,7 +121,7 @@ struct Lane16 {
     int best_t, best_r, best_j;   // best T (true, 32-bit), row index inside the lane (0..2R-1), column
 };
 
-template <int R, bool MASKED, bool TRACK, bool EMIT_ANY, bool HALF, bool PERM>
+template <int R, bool MASKED, bool TRACK, bool EMIT_ANY, bool HALF, bool PERM, bool SWF>
 __device__ __forceinline__ void wave_step16(Lane16<R>& st, WaveLds16* lds, const int u, const int lane,
                                             const int jl /* LO column of this lane at u=0 */, const int n,
                                             const int nvalid_lo, const int nvalid_hi, const int emit_lane,
@@ -164,7 +165,7 @@ __device__ __forceinline__ void wave_step16(Lane16<R>& st, WaveLds16* lds, const
         }
         s2 Ev = padd_sat(pmax(st.TL[r], st.E[r]), m2);
         const s2 v = diag + __builtin_bit_cast(s2, y);
-        const s2 g = pmax(pmax(v, Ev), Z[r]);              // off the row-to-row critical chain
+        const s2 g = SWF ? pmax(pmax(v, Ev), Z[r]) : pmax(v, Ev);   // off the row-to-row critical chain (Z: SW floor)
         const s2 Fv = pmax(upT, upF);                      // chain: max, max, add per row
         const s2 H = pmax(g, Fv);
         s2 T = H + m3;
@@ -278,7 +279,7 @@ __device__ __forceinline__ int chunk_max16(const s2 (&cm)[R]) {
 // 64 systolic steps of one chunk (reads the staged inputs from LDS, leaves the emit row in out_tf)
 struct NoService16 { __device__ __forceinline__ void operator()(int) const {} };
 
-template <int R, bool MASKED, bool TRACKSTEP, bool EMIT_ANY, bool HALF, bool PERM, typename Svc>
+template <int R, bool MASKED, bool TRACKSTEP, bool EMIT_ANY, bool HALF, bool PERM, bool SWF, typename Svc>
 __device__ __forceinline__ void run_chunk16(Lane16<R>& st, WaveLds16* lds, const int lane, const int jl, const int n,
                                             const int nvalid_lo, const int nvalid_hi, const int emit_lane,
                                             const int emit_row, const s2 (&Z)[R], const int bias, s2 (&cmax)[R],
@@ -294,11 +295,11 @@ __device__ __forceinline__ void run_chunk16(Lane16<R>& st, WaveLds16* lds, const
         if (PK16_SVC_B > 0 && ub == PK16_SVC_B) service(1);
 #pragma unroll
         for (int k = 0; k < PK16_UNROLL; k++)
-            wave_step16<R, MASKED, TRACKSTEP, EMIT_ANY, HALF, PERM>(st, lds, ub + k, lane, jl, n, nvalid_lo, nvalid_hi, emit_lane, emit_row, Z, bias, feed, c1, cmax, out_base, out_stride, all_rows_valid);
+            wave_step16<R, MASKED, TRACKSTEP, EMIT_ANY, HALF, PERM, SWF>(st, lds, ub + k, lane, jl, n, nvalid_lo, nvalid_hi, emit_lane, emit_row, Z, bias, feed, c1, cmax, out_base, out_stride, all_rows_valid);
     }
 }
 
-template <int R, bool TRACK>
+template <int R, bool TRACK, bool SWF>
 __device__ __attribute__((noinline)) void process_strip16(const KernelArgs* ap, const int s_in, WaveLds16* lds, const int lane) {
     const UniformArgs a = uniform_args(ap);
     const int s = __builtin_amdgcn_readfirstlane(s_in);
@@ -354,25 +355,29 @@ __device__ __attribute__((noinline)) void process_strip16(const KernelArgs* ap, 
     }
     Lane16<R> st;
     int h0[2 * R], e0[2 * R];
-    int hmax = 0;
+    int hmax = SWF ? 0 : NEG_INF;
 #pragma unroll
     for (int r = 0; r < R; r++) {
 #pragma unroll
         for (int half = 0; half < 2; half++) {
             const int g = (half ? lrow_hi : lrow_lo) + r;
-            int h = 0, ee = NEG_INF;
+            // rows past m: 0 is a harmless start under the SW floor; without a floor it could sit far above
+            // the window, so they start at the -INF image instead
+            int h = (SWF || a->first_col == nullptr) ? 0 : NEG_INF, ee = NEG_INF;
             if (a->first_col != nullptr && g < a->m) {
                 const int2 c = ld_sys2_16(&a->first_col[g + 1]);
                 h = c.x; ee = c.y;
             }
             h0[2 * r + half] = h; e0[2 * r + half] = ee;
-            hmax = max(hmax, h);
+            if (SWF || g < a->m) hmax = max(hmax, h);
         }
     }
     // initial window: centred on the largest first-column score of the strip (0 for zero borders)
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) hmax = max(hmax, __shfl_xor(hmax, d));
-    bias = __builtin_amdgcn_readfirstlane(hmax > REBASE_HI ? hmax - REBASE_TO : 0);
+    // SW: the window never goes below the floor (bias >= 0); NW/semi-global: it follows the scores down too
+    if (SWF) bias = __builtin_amdgcn_readfirstlane(hmax > REBASE_HI ? hmax - REBASE_TO : 0);
+    else bias = __builtin_amdgcn_readfirstlane((hmax > REBASE_HI || hmax < REBASE_LO) ? hmax - REBASE_TO : 0);
     s2 Z[R];                                              // SW floor (H = 0) of every row in its shifted domain
 #pragma unroll
     for (int r = 0; r < R; r++) Z[r] = splat(clamp16(2 * r - bias));
@@ -397,7 +402,7 @@ __device__ __attribute__((noinline)) void process_strip16(const KernelArgs* ap, 
 #pragma unroll
         for (int half = 0; half < 2; half++) {
             const int g0 = half ? lrow_hi : lrow_lo;
-            int h = 0;
+            int h = (SWF || a->first_col == nullptr) ? 0 : NEG_INF;
             if (a->first_col != nullptr && g0 <= a->m) h = ld_sys2_16(&a->first_col[g0]).x;
             hd[half] = clamp16(h - T_OFF - bias - 2);        // "row -1" of the block
         }
@@ -480,7 +485,8 @@ __device__ __attribute__((noinline)) void process_strip16(const KernelArgs* ap, 
             if (trc) q1 = __builtin_amdgcn_s_memrealtime();
             const int mk = ((code < a->n_match_codes) ? (4 << code) : 0) | 2;
             const int mkp = ((codep < a->n_match_codes) ? (4 << codep) : 0) | 2;
-            if (hf.x - T_OFF - bias > GUARD16) overflow = true;
+            if (col < n && hf.x - T_OFF - bias > GUARD16) overflow = true;
+            if (!SWF && col < n && hf.x - T_OFF - bias < -GUARD16) overflow = true;   // no floor to hide behind
             // shift the window by one chunk, then append
             const int w0 = lds->c1w[64 + lane];
             const int w1 = lds->c1w[128 + lane];
@@ -562,16 +568,16 @@ __device__ __attribute__((noinline)) void process_strip16(const KernelArgs* ap, 
         const bool use_perm = !masked && !emit_any && simple0 && simple1 && simple2;
         if (TRACK && exact_mode) {
             const int bt0 = st.best_t, bj0 = st.best_j, br0 = st.best_r;
-            if (emit_any) run_chunk16<R, true, true, true, false, false>(st, lds, lane, jl, n, nvalid_lo, nvalid_hi, emit_lane, emit_row, Z, bias, cmax, service, !ragged);
-            else if (masked) run_chunk16<R, true, true, false, false, false>(st, lds, lane, jl, n, nvalid_lo, nvalid_hi, 63, R - 1, Z, bias, cmax, service, !ragged);
-            else run_chunk16<R, false, true, false, false, false>(st, lds, lane, jl, n, nvalid_lo, nvalid_hi, 63, R - 1, Z, bias, cmax, service, !ragged);
+            if (emit_any) run_chunk16<R, true, true, true, false, false, SWF>(st, lds, lane, jl, n, nvalid_lo, nvalid_hi, emit_lane, emit_row, Z, bias, cmax, service, !ragged);
+            else if (masked) run_chunk16<R, true, true, false, false, false, SWF>(st, lds, lane, jl, n, nvalid_lo, nvalid_hi, 63, R - 1, Z, bias, cmax, service, !ragged);
+            else run_chunk16<R, false, true, false, false, false, SWF>(st, lds, lane, jl, n, nvalid_lo, nvalid_hi, 63, R - 1, Z, bias, cmax, service, !ragged);
             exact_mode = __any(st.best_t != bt0 || st.best_j != bj0 || st.best_r != br0);
         } else {
-        if (use_perm) run_chunk16<R, false, false, false, HALF, true>(st, lds, lane, jl, n, nvalid_lo, nvalid_hi, 63, R - 1, Z, bias, cmax, service);
-        else if (emit_any && masked) run_chunk16<R, true, false, true, HALF, false>(st, lds, lane, jl, n, nvalid_lo, nvalid_hi, emit_lane, emit_row, Z, bias, cmax, service);
-        else if (emit_any) run_chunk16<R, false, false, true, HALF, false>(st, lds, lane, jl, n, nvalid_lo, nvalid_hi, emit_lane, emit_row, Z, bias, cmax, service);
-        else if (masked) run_chunk16<R, true, false, false, HALF, false>(st, lds, lane, jl, n, nvalid_lo, nvalid_hi, 63, R - 1, Z, bias, cmax, service);
-        else run_chunk16<R, false, false, false, HALF, false>(st, lds, lane, jl, n, nvalid_lo, nvalid_hi, 63, R - 1, Z, bias, cmax, service);
+        if (use_perm) run_chunk16<R, false, false, false, HALF, true, SWF>(st, lds, lane, jl, n, nvalid_lo, nvalid_hi, 63, R - 1, Z, bias, cmax, service);
+        else if (emit_any && masked) run_chunk16<R, true, false, true, HALF, false, SWF>(st, lds, lane, jl, n, nvalid_lo, nvalid_hi, emit_lane, emit_row, Z, bias, cmax, service);
+        else if (emit_any) run_chunk16<R, false, false, true, HALF, false, SWF>(st, lds, lane, jl, n, nvalid_lo, nvalid_hi, emit_lane, emit_row, Z, bias, cmax, service);
+        else if (masked) run_chunk16<R, true, false, false, HALF, false, SWF>(st, lds, lane, jl, n, nvalid_lo, nvalid_hi, 63, R - 1, Z, bias, cmax, service);
+        else run_chunk16<R, false, false, false, HALF, false, SWF>(st, lds, lane, jl, n, nvalid_lo, nvalid_hi, 63, R - 1, Z, bias, cmax, service);
         if (TRACK) {
             if (__any(chunk_max16<R, HALF>(cmax) + SLACK + bias >= st.best_t)) {
 #pragma unroll
@@ -580,9 +586,9 @@ __device__ __attribute__((noinline)) void process_strip16(const KernelArgs* ap, 
                 s2 cmax2[R];
 #pragma unroll
                 for (int r = 0; r < R; r++) cmax2[r] = splat(-32768);
-                if (emit_any) run_chunk16<R, true, true, true, false, false>(st, lds, lane, jl, n, nvalid_lo, nvalid_hi, emit_lane, emit_row, Z, bias, cmax2, NoService16(), !ragged);
-                else if (masked) run_chunk16<R, true, true, false, false, false>(st, lds, lane, jl, n, nvalid_lo, nvalid_hi, 63, R - 1, Z, bias, cmax2, NoService16(), !ragged);
-                else run_chunk16<R, false, true, false, false, false>(st, lds, lane, jl, n, nvalid_lo, nvalid_hi, 63, R - 1, Z, bias, cmax2, NoService16(), !ragged);
+                if (emit_any) run_chunk16<R, true, true, true, false, false, SWF>(st, lds, lane, jl, n, nvalid_lo, nvalid_hi, emit_lane, emit_row, Z, bias, cmax2, NoService16(), !ragged);
+                else if (masked) run_chunk16<R, true, true, false, false, false, SWF>(st, lds, lane, jl, n, nvalid_lo, nvalid_hi, 63, R - 1, Z, bias, cmax2, NoService16(), !ragged);
+                else run_chunk16<R, false, true, false, false, false, SWF>(st, lds, lane, jl, n, nvalid_lo, nvalid_hi, 63, R - 1, Z, bias, cmax2, NoService16(), !ragged);
                 exact_mode = (PK16_EXACT_MODE != 0);
             }
         }
@@ -597,7 +603,7 @@ __device__ __attribute__((noinline)) void process_strip16(const KernelArgs* ap, 
             // the wave-wide maximum (six cross-lane steps) is only needed when one of its three consumers
             // can fire; three ballots decide that
             const bool need_wmax = __any(cmv + SLACK > REBASE_HI) || (TRACK && __any(cmv + bias > gseen)) ||
-                                   (bias > 0 && !__any(cmv >= 0));
+                                   (SWF ? (bias > 0 && !__any(cmv >= 0)) : !__any(cmv >= REBASE_LO));
             if (need_wmax) {
                 int w = cmv;
 #pragma unroll
@@ -608,7 +614,8 @@ __device__ __attribute__((noinline)) void process_strip16(const KernelArgs* ap, 
                 }
                 int nb = bias;
                 if (wmax + SLACK > REBASE_HI) nb = bias + (wmax - REBASE_TO);
-                else if (wmax < 0 && bias > 0 && wmax > -32768) nb = max(0, bias + max(wmax - REBASE_TO, -30000));
+                else if (SWF && wmax < 0 && bias > 0 && wmax > -32768) nb = max(0, bias + max(wmax - REBASE_TO, -30000));
+                else if (!SWF && wmax < REBASE_LO && wmax > -32768) nb = bias + max(wmax - REBASE_TO, -30000);
                 if (nb != bias) {
                     // shift every live 16-bit value by the same amount (saturating: the -INF image stays put
                     // when the window moves up); outputs of this chunk were produced with the old bias
@@ -757,7 +764,7 @@ __device__ __attribute__((noinline)) int claim_strip16(const KernelArgs* ap, con
     return __builtin_amdgcn_readfirstlane(s);
 }
 
-template <int R, bool TRACK>
+template <int R, bool TRACK, bool SWF>
 __global__ void __launch_bounds__(64) sw_strip_kernel_pk16(const KernelArgs* __restrict__ ap) {
     __shared__ WaveLds16 lds_store;
     WaveLds16* lds = &lds_store;
@@ -776,27 +783,30 @@ __global__ void __launch_bounds__(64) sw_strip_kernel_pk16(const KernelArgs* __r
             if (lane == 0) st_agent16(&a->progress[s + 1], a->n);
             __builtin_amdgcn_wave_barrier();
         } else {
-            process_strip16<R, TRACK>(ap, s, lds, lane);
+            process_strip16<R, TRACK, SWF>(ap, s, lds, lane);
         }
         complete_strip16(ap, s, lane);
     }
 }
 
-hipError_t launch_strip_kernel_pk16(const KernelArgs& a, KernelArgs* dargs, int rows_per_half, int grid, hipStream_t stream, bool track) {
+hipError_t launch_strip_kernel_pk16(const KernelArgs& a, KernelArgs* dargs, int rows_per_half, int grid, hipStream_t stream, bool track, bool sw) {
     hipError_t e = hipMemcpyAsync(dargs, &a, sizeof(KernelArgs), hipMemcpyHostToDevice, stream);
     if (e != hipSuccess) return e;
     e = hipStreamSynchronize(stream);
     if (e != hipSuccess) return e;
-#define LAUNCH16(RV, TRV) hipLaunchKernelGGL((sw_strip_kernel_pk16<RV, TRV>), dim3(grid), dim3(64), 0, stream, (const KernelArgs*) dargs)
+#define LAUNCH16(RV, TRV, SWV) hipLaunchKernelGGL((sw_strip_kernel_pk16<RV, TRV, SWV>), dim3(grid), dim3(64), 0, stream, (const KernelArgs*) dargs)
+#define LAUNCH16R(RV) do { if (sw) { if (track) LAUNCH16(RV, true, true); else LAUNCH16(RV, false, true); } \
+                           else    { if (track) LAUNCH16(RV, true, false); else LAUNCH16(RV, false, false); } } while (0)
     switch (rows_per_half) {
-    case 2: if (track) LAUNCH16(2, true); else LAUNCH16(2, false); break;
-    case 4: if (track) LAUNCH16(4, true); else LAUNCH16(4, false); break;
-    case 6: if (track) LAUNCH16(6, true); else LAUNCH16(6, false); break;
-    case 8: if (track) LAUNCH16(8, true); else LAUNCH16(8, false); break;
-    case 12: if (track) LAUNCH16(12, true); else LAUNCH16(12, false); break;
-    case 16: if (track) LAUNCH16(16, true); else LAUNCH16(16, false); break;
+    case 2: LAUNCH16R(2); break;
+    case 4: LAUNCH16R(4); break;
+    case 6: LAUNCH16R(6); break;
+    case 8: LAUNCH16R(8); break;
+    case 12: LAUNCH16R(12); break;
+    case 16: LAUNCH16R(16); break;
     default: return hipErrorInvalidValue;
     }
+#undef LAUNCH16R
 #undef LAUNCH16
     return hipGetLastError();
 }

@@ -71,6 +71,27 @@ def test_nw_and_semiglobal_edges(pkg, oracle, aligner, start, end):
     assert np.array_equal(mg.lastRow(), ref["last_row"])
     assert np.array_equal(mg.lastColumn(), ref["last_col"])
     assert tuple(mg.getBestScore()) == tuple(ref["best"])
+    assert st["profile_kernel"] == 2        # NW and the semi-global forms run on the packed kernel, no fallback
+
+
+@pytest.mark.parametrize("rel", [False, True])
+def test_packed_kernel_nw_window_follows_scores_down(pkg, oracle, aligner, rel):
+    """global alignment (gap-initialised borders) of 30 k x 45 k: scores fall far below -32768 (unrelated)
+    or swing from negative to positive (related), so the packed kernel's 16-bit window has to be re-centred
+    downwards as well as upwards -- and stay bit-exact on the last row, the last column and H[m][n]."""
+    from helpers import oracle_kwargs
+    m, n = 30000, 45000
+    s0, s1 = (pkg.seqgen.related_pair if rel else pkg.seqgen.unrelated_pair)(m, n, cfg=88)
+    mg = run_stage1(pkg, aligner, s0, s1, 4, 4, keep_last_row=True, keep_last_col=True)
+    st = aligner.getStatistics()
+    assert st["profile_kernel"] == 2 and st["kernel_launches"] == 1
+    kw = oracle_kwargs(oracle, dict(start=4, end=4, pruning=False, disk=-1, block=(st["strip_rows"], 1 << 20)), m, n)
+    kw.update(want_last_row=True, want_last_col=True)
+    ref = oracle.stage1(s0, s1, **kw)
+    assert ref["last_row"][:, 0].min() < -40000
+    assert np.array_equal(mg.lastRow(), ref["last_row"])
+    assert np.array_equal(mg.lastColumn(), ref["last_col"])
+    assert tuple(mg.getBestScore()) == tuple(ref["best"])
 
 
 def test_generic_compare_kernel_and_foreign_bytes(pkg, oracle):
