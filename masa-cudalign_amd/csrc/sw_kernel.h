@@ -64,7 +64,7 @@ __device__ __forceinline__ UniformArgs uniform_args(const KernelArgs* p) {
 // `dargs` = device copy of the argument block (the launcher uploads `a` into it on `stream`)
 hipError_t launch_strip_kernel(const KernelArgs& a, KernelArgs* dargs, int rows_per_lane, int grid, hipStream_t stream,
                                bool sw, bool profile, bool track);
-// packed 16-bit SW kernel (sw_kernel_pk16.hip): strip height = 128*rows_per_half
+// packed 16-bit SW kernel (sw_kernel_pk16.inc, instantiated by sw_kernel_pk16_{a,b,c}.hip): strip height = 128*rows_per_half
 hipError_t launch_strip_kernel_pk16(const KernelArgs& a, KernelArgs* dargs, int rows_per_half, int grid, hipStream_t stream, bool track, bool sw);
 hipError_t launch_fill_bus(int2* bus, int n, int init_type, int start_offset, hipStream_t stream);
 hipError_t launch_fill_int(int* p, long long count, int value, hipStream_t stream);

@@ -388,7 +388,7 @@ __global__ void __launch_bounds__(64) sw_strip_kernel(const KernelArgs* __restri
     const int lane = threadIdx.x;
     const UniformArgs a = uniform_args(ap);
     const int num_strips = a->num_strips;
-    // one wavefront per SIMD, enforced: see sw_kernel_pk16.hip
+    // one wavefront per SIMD, enforced: see sw_kernel_pk16.inc
     asm volatile("" ::: "a255");
     for (;;) {
         const int s = __builtin_amdgcn_readfirstlane(claim_strip(ap, lane));
