@@ -118,6 +118,7 @@ def main():
         # every strip wavefront owns a whole SIMD; RCCL's send/recv kernels need SIMDs of
         # their own, so leave 32 CUs' worth unclaimed (experimental transport -- "host" is the default)
         waves = (256 - 32) * 4
+    # N > 1: strip height from the chain model (bands.rows_per_lane_for_bands)
     lim = band_limits(n, [1] * world)
     rows_per_lane = args.rows_per_lane
     if rows_per_lane == 0 and world > 1:
@@ -186,7 +187,7 @@ def main():
             "vs_baseline": None, "dtype": "i16x2 (packed, exact; int32 fallback)" if st["profile_kernel"] == 2 else "int32",
             "data": "synthetic",
             "config": {"workload": ("C2: %dx%d unrelated random ACGT, local SW, score-only" % (m, n)) if world == 1 else
-                       ("weak scaling of C2: (%d*%d)x%d, %d column bands of %d columns, boundary column over RCCL p2p"
+                       ("weak scaling of C2: (%d*%d)x%d, %d column bands of %d columns, boundary column streamed rank g -> g+1"
                         % (args.size, world, n, world, n // world)),
                        "m": m, "n": n, "bands": world, "strip_rows": st["strip_rows"], "waves_per_gpu": st["waves"],
                        "kernel": {2: "pk16", 1: "int32-profile", 0: "int32-generic"}[st["profile_kernel"]],

@@ -31,17 +31,18 @@ def band_limits(n, weights):
 
 
 def rows_per_lane_for_bands(m, band_cols, world, waves=1024):
-    """Strip height for a chain of `world` column bands.  Band g+1 can only start once band g has swept
-    its first strips across the whole band, so the chain's start-up costs (world-1) * band_cols steps on
-    top of one band's own work; the step time grows with the strip height (runtime.cpp: 70 + 11.8*R ns)
-    while taller strips do the work itself faster.  Same cost model as the library's single-band planner
-    plus that start-up term."""
+    """Strip height for a chain of `world` equal column bands.  Band g+1 can only start once band g has
+    swept its first strips across the whole band, and can never finish earlier than one band sweep after
+    band g does, so the chain costs (rounds + world - 1) sweeps of band_cols steps; the step time grows
+    with the strip height (measured table, same as runtime.cpp step_ns) while taller strips need fewer
+    rounds.  Equal widths are optimal for such a chain (a narrower later band is throttled by its
+    predecessor's rate, a wider one by its own), so only the height is planned."""
     best, tb = 0, None
     for R in (4, 8, 12, 16, 24, 32):
-        step = 70.0 + 11.8 * R
+        step = {4: 111, 8: 151, 12: 192, 16: 223, 24: 296, 32: 406}[R]
         strips = -(-m // (64 * R))
         rounds = -(-strips // waves)
-        t = step * (rounds * band_cols + 280.0 * min(strips, waves) + (world - 1) * band_cols)
+        t = step * ((rounds + world - 1) * band_cols + 280.0 * min(strips, waves))
         if tb is None or t < tb:
             best, tb = R, t
     return best

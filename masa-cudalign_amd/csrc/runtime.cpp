@@ -281,12 +281,20 @@ int mi355sw_unset_sequences(mi355sw_handle* h) {
 // streaming form
 // ------------------------------------------------------------------------------------------------
 // Strip geometry (measured on MI355X, tools/gpu_perf.py sweeps, packed kernel, one wavefront per SIMD):
-// one systolic step of a 64*R-row strip costs about 70 + 11.8*R ns (hand-off, LDS traffic and the per-chunk
+// one systolic step of a 64*R-row strip costs step_ns(R) (hand-off, LDS traffic and the per-chunk
 // publish/poll are per step, the cell arithmetic per row), a strip follows its predecessor ~280 steps
 // behind, and the W wavefronts sweep the partition in ceil(strips/W) rounds of n steps each -- a partly
 // filled last round costs a full one.  Pick the height with the smallest estimate.
+static double step_ns(int R) {
+    switch (R) {                       // 2 rounds x 1 M columns, 1024 wavefronts: T / (2e6 + 280*1024)
+    case 4: return 111; case 8: return 151; case 12: return 192; case 16: return 223;
+    case 24: return 296; case 32: return 406;
+    default: return 60.0 + 10.5 * R;
+    }
+}
+
 static double estimate_ns(int m, int n, int R, int W) {
-    const double step = 70.0 + 11.8 * R;
+    const double step = step_ns(R);
     const long long strips = ((long long) m + 64 * R - 1) / (64 * R);
     const long long rounds = (strips + W - 1) / W;
     const long long hops = strips < W ? strips : W;
