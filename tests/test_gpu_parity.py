@@ -218,6 +218,39 @@ def test_large_roundtrip_properties(pkg, aligner):
     assert abs(a[0] - 200400) <= 40 and abs(a[1] - 120400) <= 40
 
 
+def test_c2_full_size_invariants(pkg, oracle):
+    """BASELINE config C2 at its full size (3 M x 3 M, unrelated ACGT, 9e12 cells) -- no oracle can sweep
+    that in a test, so the result is pinned through size-independent properties:
+      * three different engines agree bit for bit on (i, j, score): packed kernel with 1536-row strips,
+        packed kernel with 1024-row strips, int32 kernel;
+      * the reported cell is real: the oracle, run on the 600 x 600 window that ends at it (a local
+        alignment of that score is far shorter), computes H = score at exactly that corner and nothing
+        higher inside the window."""
+    m = n = 3000000
+    s0, s1 = pkg.seqgen.unrelated_pair(m, n, cfg=2)
+    part = pkg.Partition(0, 0, m, n)
+    results = []
+    for (R, flags, kernel) in ((24, 0, 2), (16, 0, 2), (16, 2, 1)):
+        al = pkg.MI355Aligner(device=0, rows_per_lane=R, flags=flags)
+        try:
+            al.setSequences(s0, s1)
+            mg = pkg.Stage1Manager(part)
+            al.alignPartition(part, mg)
+            st = al.getStatistics()
+            assert st["profile_kernel"] == kernel and st["strip_rows"] == 64 * R
+            results.append(tuple(mg.getBestScore()))
+        finally:
+            al.close()
+    assert results[0] == results[1] == results[2]
+    i, j, score = results[0]            # 1-based DP coordinates (dispatchScore convention)
+    assert 18 <= score <= 30
+    W = 600
+    i0, j0 = max(0, i - W), max(0, j - W)
+    ref = oracle.stage1(s0[i0:i], s1[j0:j], want_last_row=True)
+    assert ref["best"][2] == score
+    assert int(ref["last_row"][-1][0]) == score          # H at the reported cell itself
+
+
 def test_packed_kernel_rebasing_beyond_16bit(pkg, oracle):
     """scores above 32767: the packed 16-bit kernel must keep its window centred on the wavefront (re-basing)
     and stay bit-exact -- best cell, last row and last column -- and must agree with the int32 kernel."""
