@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define MI355SW_ABI_VERSION 1
+#define MI355SW_ABI_VERSION 2
 
 /* M/libmasa/libmasaTypes.hpp:35-41  cell_t {int h; union{int f; int e;};} 8-byte aligned */
 typedef struct { int32_t h; int32_t f; } mi355sw_cell;
@@ -115,6 +115,7 @@ typedef struct {
     int32_t strips, strip_rows, waves;
     int32_t profile_kernel;     /* 1 = 4-bit profile scoring, 0 = generic byte compare, 2 = packed 16-bit */
     int64_t algorithmic_bytes;  /* 17*n*ceil(m/S) + m + 8(n+1)*rows_flushed           */
+    int64_t pruned_cells;       /* cells of skipped slabs (block pruning)                        */
 } mi355sw_stats;
 
 /* ---- life cycle: IAligner::initialize/finalize (IAligner.hpp:186,226; X/CUDAligner.cpp:137-174) ---- */
@@ -172,6 +173,10 @@ typedef struct {
                                            AbstractDiagonalAligner::isSpecialRow :466-478) */
     int32_t track_best;                 /* mustDispatchScores() */
     int32_t force_int32;                /* 1: int32 kernel even where the packed 16-bit one applies */
+    int32_t prune_blocks;               /* mustPruneBlocks(): skip 64-column slabs of a strip that cannot reach the
+                                           running best (AbstractBlockPruning::isBlockPrunable, SW only) */
+    int32_t prune_rows, prune_cols;     /* rows/columns left from the partition origin to the end of the
+                                           SUPER-partition (max_i - i0, max_j - j0); 0 = the partition's own */
 } mi355sw_stream_params;
 
 int mi355sw_stream_begin(mi355sw_handle* h, const mi355sw_partition* partition, const mi355sw_stream_params* p);

@@ -219,7 +219,7 @@ int mi355sw_get_capabilities(mi355sw_handle* h, mi355sw_capabilities* c) {
     c->dispatch_special_row = 1; c->dispatch_special_column = 0;
     c->dispatch_scores = 1; c->dispatch_block_scores = 0; c->dispatch_best_score = 1;
     c->customize_first_row = 1; c->customize_first_column = 1;
-    c->process_partition = 1; c->variable_penalties = 0; c->block_pruning = 0;
+    c->process_partition = 1; c->variable_penalties = 0; c->block_pruning = 1;
     c->needleman_wunsch = 1; c->smith_waterman = 1; c->fork_processes = 1;
     c->maximum_seq0_len = 0; c->maximum_seq1_len = 0;
     return MI355SW_OK;
@@ -491,6 +491,11 @@ int mi355sw_stream_begin(mi355sw_handle* h, const mi355sw_partition* part, const
     a.strips_done_host = getenv("MI355SW_NOHOST") ? nullptr : h->h_pinned + 0;
     a.first_col_ready = (need_first_col && p->stream_first_column) ? h->h_pinned + 16 : nullptr;
     a.gbest = ctrl + 52;
+    // block pruning: packed SW kernel only (the int32 fallback and NW simply compute everything)
+    a.prune = (p->prune_blocks && h->use16 && p->recurrence_type == MI355SW_SMITH_WATERMAN) ? 1 : 0;
+    a.prune_rows = p->prune_rows > 0 ? p->prune_rows : m;
+    a.prune_cols = p->prune_cols > 0 ? p->prune_cols : n;
+    a.pruned_slabs = (unsigned long long*) (ctrl + 40);
     a.strip_best = (int4*) h->d_strip_best.p;
     a.dbg = getenv("MI355SW_DEBUG") ? ctrl + 56 : nullptr;
     a.trace = nullptr;
@@ -738,6 +743,13 @@ int mi355sw_stream_end(mi355sw_handle* h, mi355sw_score* best, int32_t* n_specia
     if (n_special_rows) *n_special_rows = h->n_special;
     const int done_strips = aborted ? ctrl[48] : h->strips;
     h->stats.processed_cells = (int64_t) std::min<long long>((long long) done_strips * h->SH, h->m) * h->n;
+    {
+        unsigned long long slabs = 0;
+        memcpy(&slabs, ctrl + 40, sizeof(slabs));
+        h->stats.pruned_cells = (int64_t) slabs * 64 * h->SH;
+        if (h->stats.pruned_cells > h->stats.processed_cells) h->stats.pruned_cells = h->stats.processed_cells;
+        h->stats.processed_cells -= h->stats.pruned_cells;
+    }
     h->processed_total += h->stats.processed_cells;
     // 17 B per column per strip + seq0 once + flushed rows
     h->stats.algorithmic_bytes = 17LL * h->n * h->strips + h->m + 8LL * (h->n + 1) * (h->n_special + (h->sp.want_last_row ? 1 : 0));
@@ -781,6 +793,14 @@ int mi355sw_align_partition(mi355sw_handle* h, const mi355sw_partition* part, co
     const bool want_last_cell = mg->must_dispatch_last_cell && mg->must_dispatch_last_cell(user);
     sp.track_best = want_scores;
     if (want_last_cell) sp.want_last_row = 1;
+    if (mg->must_prune_blocks && mg->must_prune_blocks(user)) {
+        // AbstractBlockPruning: the bound uses the extents of the SUPER-partition (M3)
+        mi355sw_partition sup = *part;
+        if (mg->get_super_partition) mg->get_super_partition(user, &sup);
+        sp.prune_blocks = 1;
+        sp.prune_rows = std::max(sup.i1, part->i1) - part->i0;
+        sp.prune_cols = std::max(sup.j1, part->j1) - part->j0;
+    }
 
     // AbstractDiagonalAligner::prepareIterations (:76-104): corner from both borders, then the row
     mi355sw_cell corner_c, corner_r;

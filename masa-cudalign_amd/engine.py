@@ -77,7 +77,7 @@ class Stats(C.Structure):
     _fields_ = [("cells", C.c_int64), ("processed_cells", C.c_int64), ("kernel_ms", C.c_double),
                 ("total_ms", C.c_double), ("kernel_launches", C.c_int32), ("strips", C.c_int32),
                 ("strip_rows", C.c_int32), ("waves", C.c_int32), ("profile_kernel", C.c_int32),
-                ("algorithmic_bytes", C.c_int64)]
+                ("algorithmic_bytes", C.c_int64), ("pruned_cells", C.c_int64)]
 
 
 class StreamParams(C.Structure):
@@ -88,7 +88,8 @@ class StreamParams(C.Structure):
                 ("stream_first_column", C.c_int32),
                 ("first_column", C.c_void_p),
                 ("want_last_column", C.c_int32), ("want_last_row", C.c_int32),
-                ("special_row_interval", C.c_int32), ("track_best", C.c_int32), ("force_int32", C.c_int32)]
+                ("special_row_interval", C.c_int32), ("track_best", C.c_int32), ("force_int32", C.c_int32),
+                ("prune_blocks", C.c_int32), ("prune_rows", C.c_int32), ("prune_cols", C.c_int32)]
 
 
 _VP = C.c_void_p
@@ -297,7 +298,7 @@ class MI355Aligner:
                     first_row_start_offset=0, first_row=None, first_column_init_type=INIT_WITH_ZEROES,
                     first_column_start_offset=0, stream_first_column=False, first_column=None,
                     want_last_column=False, want_last_row=False, special_row_interval=0, track_best=True,
-                    force_int32=False):
+                    force_int32=False, prune_blocks=False, prune_rows=0, prune_cols=0):
         sp = StreamParams()
         sp.recurrence_type = recurrence_type
         sp.first_row_init_type, sp.first_row_start_offset = first_row_init_type, first_row_start_offset
@@ -311,6 +312,7 @@ class MI355Aligner:
         sp.want_last_column, sp.want_last_row = int(want_last_column), int(want_last_row)
         sp.special_row_interval, sp.track_best = special_row_interval, int(track_best)
         sp.force_int32 = int(force_int32)
+        sp.prune_blocks, sp.prune_rows, sp.prune_cols = int(prune_blocks), int(prune_rows), int(prune_cols)
         self._check(self._lib.mi355sw_stream_begin(self._h, C.byref(partition), C.byref(sp)), "streamBegin")
         self._stream_part = partition
 

@@ -357,3 +357,51 @@ def test_special_rows_with_1536_row_strips(pkg, oracle):
             assert np.array_equal(mg.specialRow(i), want[i]), i
     finally:
         al.close()
+
+
+def test_block_pruning_keeps_the_canonical_best(pkg, oracle):
+    """mustPruneBlocks(): slabs that cannot reach the running best are skipped (AbstractBlockPruning bound).
+    On a related pair a large part of the matrix is pruned, yet best score AND canonical position equal the
+    unpruned run and the oracle; what is left in the special rows is a lower bound of the true cells that
+    is exact where it matters (each row's maximum lies on the optimal path)."""
+    m, n = 60000, 50000
+    s0, s1 = pkg.seqgen.related_pair(m, n, cfg=31)
+    ref = oracle.stage1(s0, s1, block_h=8192, block_w=n, special_row_interval=8192)
+    want_rows = dict(zip(ref["special_row_ids"], ref["special_rows"]))
+    al = pkg.MI355Aligner(device=0, rows_per_lane=4)
+    try:
+        al.setSequences(s0, s1)
+        part = pkg.Partition(0, 0, m, n)
+        out = {}
+        for prune in (False, True):
+            mg = pkg.Stage1Manager(part, special_row_interval=8192, block_pruning=prune)
+            al.alignPartition(part, mg)
+            st = al.getStatistics()
+            out[prune] = (tuple(mg.getBestScore()), st["pruned_cells"], mg)
+            assert st["profile_kernel"] == 2
+        assert out[False][0] == out[True][0] == tuple(ref["best"])
+        assert out[False][1] == 0
+        assert out[True][1] > 0.15 * m * n                       # a sizeable part of the matrix was skipped
+        assert out[True][1] + al.getStatistics()["processed_cells"] == m * n
+        mgp = out[True][2]
+        for i in sorted(mgp.special_rows):
+            got, want = mgp.specialRow(i)[:, 0], want_rows[i][:, 0]
+            assert (got <= want).all() and (got[1:] >= 0).all()
+            assert got.max() == want.max() and int(got.argmax()) == int(want.argmax())
+    finally:
+        al.close()
+
+
+def test_block_pruning_unrelated_prunes_nothing_and_nw_ignores_it(pkg, oracle):
+    m, n = 9000, 12000
+    s0, s1 = pkg.seqgen.unrelated_pair(m, n, cfg=32)
+    al = pkg.MI355Aligner(device=0)
+    try:
+        al.setSequences(s0, s1)
+        part = pkg.Partition(0, 0, m, n)
+        mg = pkg.Stage1Manager(part, block_pruning=True)
+        al.alignPartition(part, mg)
+        assert al.getStatistics()["pruned_cells"] == 0
+        assert tuple(mg.getBestScore()) == tuple(oracle.stage1(s0, s1)["best"])
+    finally:
+        al.close()
