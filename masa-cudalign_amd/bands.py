@@ -63,8 +63,9 @@ class BandRunner:
     """Runs one band of the chain on this rank.  `dist` is torch.distributed (already initialised)
     or None for a single band.  All ranks must call run() with the same m, n, weights, segment."""
 
-    def __init__(self, engine, dist=None, rank=0, world=1, device=None, segment_rows=1 << 16):
+    def __init__(self, engine, dist=None, rank=0, world=1, device=None, segment_rows=1 << 16, prune_blocks=False):
         self.engine, self.dist, self.rank, self.world = engine, dist, rank, world
+        self.prune_blocks = prune_blocks
         self.device = device
         self.segment_rows = segment_rows
 
@@ -82,7 +83,10 @@ class BandRunner:
         nseg = (m + seg - 1) // seg
         kw = dict(recurrence_type=recurrence, track_best=track_best,
                   first_row_init_type=first_row_init_type, first_row_start_offset=j0,
-                  want_last_column=not last)
+                  want_last_column=not last,
+                  # block pruning: never when the matrix is split over processes (as the reference,
+                  # libmasa.cpp:1318-1321); for a single band it is the caller's choice (self.prune_blocks)
+                  prune_blocks=(self.prune_blocks and self.world == 1 and recurrence == SMITH_WATERMAN and track_best))
         if first:
             kw.update(first_column_init_type=first_col_init_type)
         else:

@@ -1,3 +1,3 @@
-// packed strip kernel, instantiation part 0 of 3 (see the end of sw_kernel_pk16.inc)
+// packed strip kernel, instantiation part 0 of 6 (see the end of sw_kernel_pk16.inc)
 #define PK16_PART 0
 #include "sw_kernel_pk16.inc"

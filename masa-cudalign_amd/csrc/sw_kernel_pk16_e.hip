@@ -1,0 +1,3 @@
+// packed strip kernel, instantiation part 4 of 6 (see the end of sw_kernel_pk16.inc)
+#define PK16_PART 4
+#include "sw_kernel_pk16.inc"

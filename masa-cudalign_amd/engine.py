@@ -133,7 +133,7 @@ _lib = None
 def build_library(force=False):
     """Compile csrc/ for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
     src = os.path.join(HERE, "csrc")
-    deps = [os.path.join(src, f) for f in ("runtime.cpp", "sw_kernel.hip", "sw_kernel_pk16.inc", "sw_kernel_pk16_a.hip", "sw_kernel_pk16_b.hip", "sw_kernel_pk16_c.hip", "sw_kernel.h")] + [INCLUDE_PATH]
+    deps = [os.path.join(src, f) for f in ("runtime.cpp", "sw_kernel.hip", "sw_kernel_pk16.inc", "sw_kernel_pk16_a.hip", "sw_kernel_pk16_b.hip", "sw_kernel_pk16_c.hip", "sw_kernel_pk16_d.hip", "sw_kernel_pk16_e.hip", "sw_kernel_pk16_f.hip", "sw_kernel.h")] + [INCLUDE_PATH]
     if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
         return LIB_PATH
     subprocess.check_call(["make", "-C", src], stdout=subprocess.DEVNULL)
