@@ -405,3 +405,53 @@ def test_block_pruning_unrelated_prunes_nothing_and_nw_ignores_it(pkg, oracle):
         assert tuple(mg.getBestScore()) == tuple(oracle.stage1(s0, s1)["best"])
     finally:
         al.close()
+
+
+def _fuzz_case(k):
+    rng = np.random.default_rng(1000 + k)
+    m = int(rng.choice([1, 2, 63, 64, 65, 127, 128, 129, 255, 300, 511, 777, 1024, 1500, 2049, 2600]))
+    n = int(rng.choice([1, 2, 63, 64, 65, 127, 128, 129, 191, 192, 193, 300, 511, 900, 1300, 2500]))
+    alpha = [b"ACGT", b"ACGT", b"ACGTN", b"ACG", b"AC", b"ACGTNRYKM", b"ACGTU"][int(rng.integers(0, 7))]
+    a = np.frombuffer(alpha, dtype=np.uint8)
+    s0 = rng.choice(a, size=m)
+    if rng.random() < 0.6 and m > 8 and n > 8:           # related: copy of a piece of seq0 with noise
+        s1 = rng.choice(a, size=n)
+        L = int(min(m, n) * rng.uniform(0.3, 1.0))
+        i0, j0 = int(rng.integers(0, m - L + 1)), int(rng.integers(0, n - L + 1))
+        piece = s0[i0:i0 + L].copy()
+        hit = rng.random(L) < 0.05
+        piece[hit] = rng.choice(a, size=int(hit.sum()))
+        s1[j0:j0 + L] = piece
+    else:
+        s1 = rng.choice(a, size=n)
+    R = int(rng.choice([0, 4, 8, 12, 16, 24, 32]))
+    start, end = [(0, 0), (0, 0), (0, 0), (4, 4), (1, 3), (2, 3), (3, 3), (1, 1), (2, 2)][int(rng.integers(0, 9))]
+    prune = bool(rng.integers(0, 2)) and (start, end) == (0, 0)
+    flags = 2 if rng.random() < 0.15 else 0               # sometimes the int32 kernel
+    return m, n, s0, s1, R, start, end, prune, flags
+
+
+@pytest.mark.parametrize("k", range(240))
+def test_randomised_differential_against_oracle(pkg, oracle, k):
+    """240 seeded random configurations (sizes around every lane / chunk / strip boundary, 2-9 letter alphabets,
+    related and unrelated pairs, every strip height, SW / NW / semi-global edges, pruning, both kernel
+    families): best cell, last row and last column equal the oracle's, bit for bit."""
+    from helpers import oracle_kwargs
+    m, n, s0, s1, R, start, end, prune, flags = _fuzz_case(k)
+    al = pkg.MI355Aligner(device=0, rows_per_lane=R, flags=flags)
+    try:
+        al.setSequences(s0, s1)
+        part = pkg.Partition(0, 0, m, n)
+        mg = pkg.Stage1Manager(part, alignment_start=getattr(pkg, EDGE[start]), alignment_end=getattr(pkg, EDGE[end]),
+                               keep_last_row=True, keep_last_column=True, block_pruning=prune)
+        al.alignPartition(part, mg)
+        st = al.getStatistics()
+        kw = oracle_kwargs(oracle, dict(start=start, end=end, pruning=False, disk=-1, block=(st["strip_rows"], 1 << 20)), m, n)
+        kw.update(want_last_row=True, want_last_col=True)
+        ref = oracle.stage1(s0, s1, **kw)
+        assert tuple(mg.getBestScore()) == tuple(ref["best"])
+        if not (prune and st["pruned_cells"] > 0):
+            assert np.array_equal(mg.lastRow(), ref["last_row"])
+            assert np.array_equal(mg.lastColumn(), ref["last_col"])
+    finally:
+        al.close()
