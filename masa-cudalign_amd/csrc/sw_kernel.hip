@@ -179,6 +179,9 @@ __device__ __attribute__((noinline)) void process_strip(const KernelArgs* ap, co
     const int rows_left = a->m - lrow0;
     const int nvalid = rows_left < 0 ? 0 : (rows_left > R ? R : rows_left);
     const int* prog_in = &a->progress[s];              // progress of the strip above
+    // wait budget of the in-kernel polls: a band fed by another GPU may legitimately stand still for as long as
+    // its first column takes to arrive (the first strip waits on the host counter, all others on that strip)
+    const int spin_limit = a->first_col_ready != nullptr ? (1 << 28) : (1 << 24);
     int* prog_out = &a->progress[s + 1];
 
     // which (lane,row) is the row handed to the next strip / flushed as special row
@@ -252,11 +255,11 @@ __device__ __attribute__((noinline)) void process_strip(const KernelArgs* ap, co
             if (need > n) need = n;
             if (col0 < n) {
                 int spins = 0;
-                while (poll_agent(prog_in) < need && spins < (1 << 24)) {
+                while (poll_agent(prog_in) < need && spins < spin_limit) {
                     __builtin_amdgcn_s_sleep(2);
                     spins++;
                 }
-                if (spins >= (1 << 24) && lane == 0) atomicExch(a->error_flag, 1);
+                if (spins >= spin_limit && lane == 0) atomicExch(a->error_flag, 1);
             }
             const int col = col0 + lane;
             int2 hf = make_int2(0, NEG_INF);
@@ -360,12 +363,14 @@ __device__ __attribute__((noinline)) void complete_strip(const KernelArgs* ap, c
     const int s = __builtin_amdgcn_readfirstlane(s_in);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
     int spins = 0;
-    while (poll_agent(a->strips_done_dev) != s && spins < (1 << 24)) {
+    // a band fed by another GPU may legitimately stand still for as long as its first column takes to arrive
+    const int spin_limit = a->first_col_ready != nullptr ? (1 << 28) : (1 << 24);
+    while (poll_agent(a->strips_done_dev) != s && spins < spin_limit) {
         __builtin_amdgcn_s_sleep(8);
         spins++;
     }
     if (lane == 0) {
-        if (spins >= (1 << 24)) atomicExch(a->error_flag, 3);
+        if (spins >= spin_limit) atomicExch(a->error_flag, 3);
         if (a->strips_done_host != nullptr)
             __hip_atomic_store(a->strips_done_host, s + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         st_agent(a->strips_done_dev, s + 1);
