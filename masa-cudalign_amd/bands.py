@@ -39,7 +39,7 @@ def rows_per_lane_for_bands(m, band_cols, world, waves=1024):
     predecessor's rate, a wider one by its own), so only the height is planned."""
     best, tb = 0, None
     for R in (4, 8, 12, 16, 24, 32):
-        step = {4: 111, 8: 151, 12: 192, 16: 223, 24: 296, 32: 406}[R]
+        step = {4: 97, 8: 138, 12: 181, 16: 222, 24: 291, 32: 368}[R]
         strips = -(-m // (64 * R))
         rounds = -(-strips // waves)
         t = step * ((rounds + world - 1) * band_cols + 280.0 * min(strips, waves))

@@ -287,8 +287,8 @@ int mi355sw_unset_sequences(mi355sw_handle* h) {
 // filled last round costs a full one.  Pick the height with the smallest estimate.
 static double step_ns(int R) {
     switch (R) {                       // 2 rounds x 1 M columns, 1024 wavefronts: T / (2e6 + 280*1024)
-    case 4: return 111; case 8: return 151; case 12: return 192; case 16: return 223;
-    case 24: return 296; case 32: return 406;
+    case 4: return 97; case 8: return 138; case 12: return 181; case 16: return 222;
+    case 24: return 291; case 32: return 368;
     default: return 60.0 + 10.5 * R;
     }
 }
