@@ -65,7 +65,7 @@ struct mi355sw_handle {
     int n_match_codes = 0, pad_code = 0;
 
     // work buffers
-    DevBuf d_bus, d_first_col, d_special, d_last_row, d_progress, d_strip_best, d_ctrl, d_kargs, d_trace, d_ckpt;
+    DevBuf d_bus, d_first_col, d_special, d_last_row, d_progress, d_strip_best, d_ctrl, d_kargs, d_trace, d_ckpt, d_seed;
     PinBuf p_first_col, p_last_col;  // streamed first column / last column (zero-copy)
     bool first_col_pinned = false;
     int* h_pinned = nullptr;        // [0] strips_done (kernel->host) [16] first_col_ready (host->kernel)
@@ -199,7 +199,7 @@ void mi355sw_destroy(mi355sw_handle* h) {
     if (h->p_first_col.p) (void) hipHostFree(h->p_first_col.p);
     if (h->p_last_col.p) (void) hipHostFree(h->p_last_col.p);
     release(h->d_special); release(h->d_last_row); release(h->d_progress);
-    release(h->d_strip_best); release(h->d_ctrl); release(h->d_kargs); release(h->d_ckpt); release(h->d_trace);
+    release(h->d_strip_best); release(h->d_ctrl); release(h->d_kargs); release(h->d_ckpt); release(h->d_trace); release(h->d_seed);
     if (h->h_pinned) (void) hipHostFree(h->h_pinned);
     if (h->ev0) (void) hipEventDestroy(h->ev0);
     if (h->ev1) (void) hipEventDestroy(h->ev1);
@@ -519,6 +519,43 @@ int mi355sw_stream_begin(mi355sw_handle* h, const mi355sw_partition* part, const
     HIPCHK(h, hipEventRecord(h->ev0, h->stream));
     h->kargs = a;
     h->exact_ms = 0;
+    // Seed pass (local alignment with exact tracking only).  Every strip starts its sweep with the exact
+    // bookkeeping switched on until the running best has risen above the background level, and in the first
+    // round nobody has found anything yet: the start-up delay of every hop of the strip pipeline is ~50 %
+    // longer than later on.  A throw-away launch first lets the same wavefronts sweep SEED_COLS columns of
+    // their own rows with all dependencies pre-satisfied (zero top border, or whatever the strip above has
+    // just written: either way a lower bound of the true cells, so every score it sees is the score of a
+    // real local alignment) and publish the maximum; 0.5 ms for ~3e9 cells.
+    if (h->use16 && p->recurrence_type == MI355SW_SMITH_WATERMAN && p->track_best && !h->two_phase &&
+        h->strips >= 64 && n >= 16384 && !getenv("MI355SW_NOSEED")) {
+        const int SEED_COLS = 2048;
+        const int ws = std::min(h->strips, waves);
+        const size_t o_ctrl = 256, o_prog = 512, o_sb = o_prog + (((size_t) ws + 1) * 8 + 255) / 256 * 256;
+        const size_t o_bus = o_sb + (size_t) ws * sizeof(int4);
+        if ((rc = ensure(h, h->d_seed, o_bus + sizeof(int2) * (SEED_COLS + 64)))) return rc;
+        char* base = (char*) h->d_seed.p;
+        int* ctrl2 = (int*) (base + o_ctrl);
+        KernelArgs b = a;
+        b.n = SEED_COLS;
+        b.m = (int) std::min<long long>(m, (long long) ws * h->SH);
+        b.num_strips = (b.m + h->SH - 1) / h->SH;
+        b.bus = (int2*) (base + o_bus);
+        b.first_col = nullptr; b.last_col = nullptr; b.special_rows = nullptr; b.special_interval_strips = 0;
+        b.last_row = nullptr; b.ckpt_rows = nullptr; b.ckpt_interval_strips = 0;
+        b.progress = (int*) (base + o_prog);
+        b.ticket = ctrl2 + 0; b.abort_flag = ctrl2 + 16; b.error_flag = ctrl2 + 32; b.strips_done_dev = ctrl2 + 48;
+        b.strips_done_host = nullptr; b.first_col_ready = nullptr;
+        b.strip_best = (int4*) (base + o_sb);
+        b.dbg = nullptr; b.trace = nullptr;
+        b.independent = 1;                             // nobody waits for anybody: progress[0..ws] stays "all columns ready"
+        b.prune = 1;                                   // selects the variant that publishes the running best without tracking positions
+        b.prune_rows = m; b.prune_cols = n;            // ... and never prunes: the bound sees the whole matrix ahead
+        b.pruned_slabs = (unsigned long long*) (ctrl2 + 40);
+        HIPCHK(h, hipMemsetAsync(base + o_ctrl, 0, 256, h->stream));
+        HIPCHK(h, launch_fill_int(b.progress, 2 * ((long long) ws + 1), SEED_COLS, h->stream));
+        HIPCHK(h, launch_fill_bus(b.bus, SEED_COLS, MI355SW_INIT_WITH_ZEROES, 0, h->stream));
+        HIPCHK(h, launch_strip_kernel_pk16(b, (KernelArgs*) base, h->R / 2, ws, h->stream, false, true));
+    }
     if (h->use16) {
         h->stats.profile_kernel = 2;
         HIPCHK(h, launch_strip_kernel_pk16(a, (KernelArgs*) h->d_kargs.p, h->R / 2, waves, h->stream,

@@ -43,6 +43,7 @@ struct KernelArgs {
     int* strips_done_host;       // pinned host mirror (system scope)
     int* gbest;                  // running global best (T domain): lower bound that seeds every lane's threshold
     int4* strip_best;            // per strip {score, i, j, valid}
+    int independent;             // seed pass: strips do not feed each other (progress is published into a dummy area)
     int prune;                   // block pruning on (packed SW kernel): skip slabs that cannot reach the running best
     int prune_rows, prune_cols;  // rows / columns from the partition origin to the end of the super-partition
     unsigned long long* pruned_slabs;   // device counter of skipped 64-step slabs
