@@ -5,7 +5,7 @@ set -e
 name=$1; shift
 cd "$(dirname "$0")/../masa-cudalign_amd/csrc"
 mkdir -p _var
-hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -w -mllvm -amdgpu-sched-strategy=max-ilp "$@" -c sw_kernel_pk16_b.hip -o _var/b_$name.o
+./hipcc_aligned.sh sw_kernel_pk16_b.hip _var/b_$name.o -O3 -std=c++17 -fPIC -w -mllvm -amdgpu-sched-strategy=max-ilp "$@"
 objs=$(ls _obj/*.o | grep -v sw_kernel_pk16_b.o)
 hipcc --offload-arch=gfx950 -shared $objs _var/b_$name.o -o ../../tools/_var_$name.so
 echo built tools/_var_$name.so

@@ -1,0 +1,144 @@
+"""Full-size runs of the BASELINE configurations that no oracle can sweep, pinned through size-independent
+properties.  python tools/scale_run.py <case> [out.json]
+
+  c3      48M x 46M related pair, local SW, special rows every ~2.4M rows: block pruning ON and OFF must report
+          the same best cell; every special row of the pruned run is a lower bound of the unpruned one; the row
+          maxima of rows above the best cell agree; sha256 of the unpruned rows recorded
+  tall    228M x 1M unrelated SW (the north-star height; two-phase best tracking, no 2^27 limit): best cell
+          confirmed by the oracle on the window that ends at it
+  wide    1M x 228M unrelated SW (the north-star width: 1.8 GB bus row): same check
+  c2x     3M x 3M with special rows + last row + last column requested (everything C2 can dispatch at once)
+"""
+import hashlib, json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import __graft_entry__ as g
+
+pkg = g.load_package()
+
+
+def run(al, part, before_end=None, **kw):
+    t0 = time.time()
+    al.streamBegin(part, **kw)
+    while True:
+        rows, fin = al.streamPoll()
+        if fin:
+            break
+        time.sleep(0.01)
+    t_done = time.time()
+    extra = before_end(al) if before_end else None      # special rows are readable while the stream is open
+    t0 += time.time() - t_done
+    best, nsp = al.streamEnd()
+    st = al.getStatistics()
+    m, n = part.getHeight(), part.getWidth()
+    info = {"best": list(best), "special_rows": nsp, "kernel_ms": st["kernel_ms"], "wall_s": time.time() - t0,
+            "gcups_mn": m * n / st["kernel_ms"] / 1e6, "strip_rows": st["strip_rows"], "strips": st["strips"],
+            "kernel": {1: "int32", 2: "pk16"}.get(st["profile_kernel"], st["profile_kernel"]),
+            "pruned_fraction": st["pruned_cells"] / st["cells"] if st["cells"] else 0.0}
+    print(json.dumps(info), flush=True)
+    if extra is not None:
+        info["rows"] = extra
+    return info
+
+
+def window_check(s0, s1, best, W=600):
+    """the oracle on the W x W window that ends at the reported cell (an unrelated pair's best local alignment is
+    far shorter than W): H at the corner equals the score and nothing inside is higher"""
+    oracle = g.load_oracle()
+    i, j, score = best                      # 0-based cell index of the stream API
+    i1, j1 = i + 1, j + 1
+    i0, j0 = max(0, i1 - W), max(0, j1 - W)
+    ref = oracle.stage1(s0[i0:i1], s1[j0:j1], want_last_row=True)
+    ok = (ref["best"][2] == score) and int(ref["last_row"][-1][0]) == score
+    return {"window": W, "oracle_best_in_window": int(ref["best"][2]), "oracle_H_at_cell": int(ref["last_row"][-1][0]),
+            "ok": bool(ok)}
+
+
+def case_unrelated(m, n, cfg, out):
+    s0, s1 = pkg.seqgen.unrelated_pair(m, n, cfg=cfg)
+    al = pkg.MI355Aligner(device=0)
+    al.setSequences(s0, s1)
+    part = pkg.Partition(0, 0, m, n)
+    r = run(al, part)
+    al.close()
+    r["check"] = window_check(s0, s1, r["best"])
+    out.update(r)
+    assert r["check"]["ok"], r["check"]
+
+
+def case_c3(out, m=48000000, n=46000000):
+    t0 = time.time()
+    s0, s1 = pkg.seqgen.related_pair(m, n, cfg=3)
+    out["generate_s"] = time.time() - t0
+    al = pkg.MI355Aligner(device=0, max_special_bytes=64 << 30)
+    al.setSequences(s0, s1)
+    part = pkg.Partition(0, 0, m, n)
+    interval = m // 20
+    rows_h = {}
+    for prune in (False, True):
+        def read_rows(al, prune=prune):
+            rows, k = [], 0
+            while True:
+                try:
+                    dp, cells = al.streamReadSpecialRow(k)
+                except pkg.engine.AlignerError:
+                    break
+                h = np.ascontiguousarray(cells[:, 0])
+                rec = {"dp_row": int(dp), "max_h": int(h.max()), "argmax": int(h.argmax())}
+                if not prune:
+                    rec["sha256"] = hashlib.sha256(np.ascontiguousarray(cells).tobytes()).hexdigest()
+                    rows_h[k] = h
+                else:
+                    ref = rows_h[k]
+                    rec["lower_bound_of_unpruned"] = bool((h <= ref).all())
+                    rec["cells_equal"] = float((h == ref).mean())
+                    rec["max_equal"] = bool(int(ref.max()) == rec["max_h"])
+                rows.append(rec)
+                k += 1
+            return rows
+        r = run(al, part, before_end=read_rows, prune_blocks=prune, special_row_interval=interval)
+        assert len(r["rows"]) == r["special_rows"], (len(r["rows"]), r["special_rows"])
+        out["pruned" if prune else "unpruned"] = r
+    al.close()
+    a, b = out["unpruned"], out["pruned"]
+    out["same_best"] = a["best"] == b["best"]
+    bi = a["best"][0]
+    out["rows_lower_bound"] = all(x["lower_bound_of_unpruned"] for x in b["rows"])
+    # rows the optimal alignment crosses carry its score exactly; below the best cell nothing is promised
+    out["row_max_equal_above_best"] = all(x["max_equal"] for x in b["rows"] if x["dp_row"] <= bi)
+    assert out["same_best"] and out["rows_lower_bound"] and out["row_max_equal_above_best"], out
+
+
+def case_c2x(out, m=3000000, n=3000000):
+    s0, s1 = pkg.seqgen.unrelated_pair(m, n, cfg=2)
+    al = pkg.MI355Aligner(device=0)
+    al.setSequences(s0, s1)
+    part = pkg.Partition(0, 0, m, n)
+    plain = run(al, part)
+    full = run(al, part, special_row_interval=m // 16, want_last_row=True, want_last_column=True)
+    out["plain"], out["full"] = plain, full
+    out["same_best"] = plain["best"] == full["best"]
+    al.close()
+    assert out["same_best"]
+
+
+if __name__ == "__main__":
+    case = sys.argv[1]
+    out = {"case": case}
+    if case == "c3":
+        case_c3(out)
+    elif case == "c3small":
+        case_c3(out, 6000000, 5000000)
+    elif case == "tall":
+        case_unrelated(228000000, 1000000, 11, out)
+    elif case == "wide":
+        case_unrelated(1000000, 228000000, 12, out)
+    elif case == "tallsmall":
+        case_unrelated(40000000, 100000, 11, out)
+    elif case == "c2x":
+        case_c2x(out)
+    else:
+        sys.exit("unknown case")
+    print(json.dumps(out, indent=1))
+    if len(sys.argv) > 2:
+        json.dump(out, open(sys.argv[2], "w"), indent=1)
