@@ -96,15 +96,26 @@ def main():
             raise SystemExit("launch N>1 with torch.distributed.run (one rank per GPU)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; the engine has no CPU fallback")
+    # MI355SW_BENCH_REHEARSAL=1: run the N>1 path on a ONE-GPU box (every rank on cuda:0, gloo instead of RCCL for
+    # the collectives, --waves small enough for all ranks' strip kernels to be resident together).  It exercises
+    # the band driver, the column transport and the result line; its numbers mean nothing.
+    rehearse = os.environ.get("MI355SW_BENCH_REHEARSAL") == "1"
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    coll_device = torch.device("cpu") if rehearse else device
     # boundary-column transport between bands: "host" = pinned zero-copy columns + gloo between the
     # rank processes (no GPU queue involved while the persistent kernels run; default), "nccl" = RCCL
     # send/recv of device tensors over xGMI (needs free CU resources next to the strip kernel)
     comm = os.environ.get("MI355SW_BENCH_COMM", "host")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if rehearse:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            comm = "host"
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
         p2p_group = dist.new_group(backend="gloo") if comm != "nccl" else None
 
     pkg = graft.load_package()
@@ -114,6 +125,8 @@ def main():
     m = args.size * world
     s0, s1 = pkg.seqgen.unrelated_pair(m, n, cfg=2)
     waves = args.waves
+    if rehearse and waves == 0:
+        waves = 1024 // world // 2        # all ranks' strip kernels must be resident on the one GPU together
     if waves == 0 and world > 1 and comm == "nccl":
         # every strip wavefront owns a whole SIMD; RCCL's send/recv kernels need SIMDs of
         # their own, so leave 32 CUs' worth unclaimed (experimental transport -- "host" is the default)
@@ -146,7 +159,7 @@ def main():
     runner = BandRunner(al, dist=_Dist() if world > 1 else None, rank=rank, world=world,
                         device=(device if (world > 1 and comm == "nccl") else None), segment_rows=1 << 15)
     if world > 1 and comm != "nccl":
-        runner.reduce_best = lambda b, _r=runner: _reduce_cpu(dist, b, world, device)
+        runner.reduce_best = lambda b, _r=runner: _reduce_cpu(dist, b, world, coll_device)
 
     def one_step():
         best = runner.run(m, j0, j1)
@@ -171,7 +184,7 @@ def main():
     fence()
     dt = time.time() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        t = torch.tensor([dt], dtype=torch.float64, device=coll_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
