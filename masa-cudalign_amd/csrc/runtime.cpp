@@ -68,7 +68,7 @@ struct mi355sw_handle {
     DevBuf d_bus, d_first_col, d_special, d_last_row, d_progress, d_strip_best, d_ctrl, d_kargs, d_trace, d_ckpt, d_seed;
     PinBuf p_first_col, p_last_col;  // streamed first column / last column (zero-copy)
     bool first_col_pinned = false;
-    int* h_pinned = nullptr;        // [0] strips_done (kernel->host) [16] first_col_ready (host->kernel)
+    int* h_pinned = nullptr;        // [0] strips_done (kernel->host) [16] first_col_ready (host->kernel) [32] abort (host->kernel)
     std::vector<int4> strip_best_host;
 
     // stream state
@@ -490,6 +490,8 @@ int mi355sw_stream_begin(mi355sw_handle* h, const mi355sw_partition* part, const
     a.strips_done_dev = ctrl + 48;
     a.strips_done_host = getenv("MI355SW_NOHOST") ? nullptr : h->h_pinned + 0;
     a.first_col_ready = (need_first_col && p->stream_first_column) ? h->h_pinned + 16 : nullptr;
+    __atomic_store_n(&h->h_pinned[32], 0, __ATOMIC_RELEASE);
+    a.host_abort = h->h_pinned + 32;
     a.gbest = ctrl + 52;
     // block pruning: packed SW kernel only (the int32 fallback and NW simply compute everything)
     a.prune = (p->prune_blocks && h->use16 && p->recurrence_type == MI355SW_SMITH_WATERMAN) ? 1 : 0;
@@ -544,7 +546,7 @@ int mi355sw_stream_begin(mi355sw_handle* h, const mi355sw_partition* part, const
         b.last_row = nullptr; b.ckpt_rows = nullptr; b.ckpt_interval_strips = 0;
         b.progress = (int*) (base + o_prog);
         b.ticket = ctrl2 + 0; b.abort_flag = ctrl2 + 16; b.error_flag = ctrl2 + 32; b.strips_done_dev = ctrl2 + 48;
-        b.strips_done_host = nullptr; b.first_col_ready = nullptr;
+        b.strips_done_host = nullptr; b.first_col_ready = nullptr; b.host_abort = nullptr;
         b.strip_best = (int4*) (base + o_sb);
         b.dbg = nullptr; b.trace = nullptr;
         b.independent = 1;                             // nobody waits for anybody: progress[0..ws] stays "all columns ready"
@@ -617,16 +619,18 @@ void* mi355sw_stream_device_last_column(mi355sw_handle* h) { return h ? h->p_las
 
 int mi355sw_stream_poll(mi355sw_handle* h, int32_t* rows_done, int32_t* finished) {
     if (!h || !h->active) return MI355SW_ESTATE;
-    const int done = __atomic_load_n(&h->h_pinned[0], __ATOMIC_ACQUIRE);
-    h->prog_strips = done;
-    long long rows = (long long) done * h->SH;
-    if (rows > h->m) rows = h->m;
-    if (rows_done) *rows_done = (int32_t) rows;
+    // completion FIRST, the strip counter second: a kernel that ends between the two reads must not be reported as
+    // "finished with rows missing" (the caller takes that for an aborted run and drops the rest of the last column)
     if (!h->finished) {
         hipError_t e = hipEventQuery(h->ev1);
         if (e == hipSuccess) h->finished = true;
         else if (e != hipErrorNotReady) FAIL(h, MI355SW_EHIP, "kernel failed: %s", hipGetErrorString(e));
     }
+    const int done = __atomic_load_n(&h->h_pinned[0], __ATOMIC_ACQUIRE);
+    h->prog_strips = done;
+    long long rows = (long long) done * h->SH;
+    if (rows > h->m) rows = h->m;
+    if (rows_done) *rows_done = (int32_t) rows;
     if (finished) *finished = h->finished ? 1 : 0;
     return MI355SW_OK;
 }
@@ -668,9 +672,9 @@ int mi355sw_stream_read_last_row(mi355sw_handle* h, mi355sw_cell* cells, int32_t
 
 int mi355sw_stream_abort(mi355sw_handle* h) {
     if (!h || !h->active) return MI355SW_ESTATE;
-    int one = 1;
-    HIPCHK(h, hipMemcpyAsync((int*) h->d_ctrl.p + 16, &one, sizeof(int), hipMemcpyHostToDevice, h->copy));
-    HIPCHK(h, hipStreamSynchronize(h->copy));
+    // a store into pinned memory the kernel polls with system scope: a copy, whatever its stream, may be held
+    // back until the persistent kernel has left the queue it was mapped to -- and then stops nothing
+    __atomic_store_n(&h->h_pinned[32], 1, __ATOMIC_RELEASE);
     // unblock strips waiting for first-column rows that will never come
     __atomic_store_n(&h->h_pinned[16], h->m, __ATOMIC_RELEASE);
     return MI355SW_OK;
@@ -736,9 +740,13 @@ int mi355sw_stream_end(mi355sw_handle* h, mi355sw_score* best, int32_t* n_specia
     h->stats.total_ms = now_ms() - h->stats.total_ms;
     int ctrl[64];
     HIPCHK(h, hipMemcpy(ctrl, h->d_ctrl.p, sizeof(ctrl), hipMemcpyDeviceToHost));
-    const bool aborted = ctrl[16] != 0;
-    if (ctrl[32] == 16) FAIL(h, MI355SW_EOVERFLOW16, "packed 16-bit kernel left its exact range; rerun with force_int32");
-    if (ctrl[32] != 0) FAIL(h, MI355SW_ETIMEOUT, "in-kernel wait timed out (code %d)", ctrl[32]);
+    const bool aborted = ctrl[16] != 0 || __atomic_load_n(&h->h_pinned[32], __ATOMIC_ACQUIRE) != 0;
+    // after a host stop the strips still in flight give up mid-sweep and their followers read stale bus cells:
+    // whatever those raise is void like the rest of their output (a genuine overflow stops the kernel by itself,
+    // the host then never sees the goal and never says stop)
+    const bool host_stopped = __atomic_load_n(&h->h_pinned[32], __ATOMIC_ACQUIRE) != 0;
+    if (ctrl[32] == 16 && !host_stopped) FAIL(h, MI355SW_EOVERFLOW16, "packed 16-bit kernel left its exact range; rerun with force_int32");
+    if (ctrl[32] != 0 && !host_stopped) FAIL(h, MI355SW_ETIMEOUT, "in-kernel wait timed out (code %d)", ctrl[32]);
     if (getenv("MI355SW_TRACE") && h->d_trace.p) {
         std::vector<long long> tr((size_t) h->strips * 4);
         HIPCHK(h, hipMemcpy(tr.data(), h->d_trace.p, tr.size() * sizeof(long long), hipMemcpyDeviceToHost));

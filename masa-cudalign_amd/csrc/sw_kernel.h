@@ -36,7 +36,9 @@ struct KernelArgs {
     // synchronisation / results
     int* progress;               // num_strips+1 ints; progress[0] = n (virtual strip above)
     int* ticket;                 // next strip to claim
-    int* abort_flag;             // host sets != 0 to stop (mustContinue() == false)
+    int* abort_flag;             // device word: the kernel sets it on an overflow report; strips claimed afterwards are skipped
+    const int* host_abort;       // pinned host word: the host sets it != 0 to stop (mustContinue() == false) -- a store,
+                                 // not a copy, because no copy may be queued while the persistent kernel runs
     int* error_flag;             // set by the kernel on a bounded-spin timeout
     const int* first_col_ready;  // pinned host counter: rows of first_col that are valid, or nullptr (all)
     int* strips_done_dev;        // device counter, ordered: value s means strips [0,s) complete

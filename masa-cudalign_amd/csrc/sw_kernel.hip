@@ -398,7 +398,7 @@ __global__ void __launch_bounds__(64) sw_strip_kernel(const KernelArgs* __restri
     for (;;) {
         const int s = __builtin_amdgcn_readfirstlane(claim_strip(ap, lane));
         if (s >= num_strips) break;
-        if (poll_agent(a->abort_flag) != 0) {
+        if (poll_agent(a->abort_flag) != 0 || (a->host_abort != nullptr && poll_sys(a->host_abort) != 0)) {
             // publish completion so that followers do not spin forever
             if (lane == 0) st_agent(&a->progress[s + 1], a->n);
             __builtin_amdgcn_wave_barrier();
