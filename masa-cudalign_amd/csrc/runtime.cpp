@@ -89,6 +89,7 @@ struct mi355sw_handle {
     bool finished = false;
     mi355sw_stats stats{};
     std::atomic<long long> processed_total{0};
+    int abort_strips = -1;          // host stop: strips complete or in flight at that moment (the rest were skipped)
     std::atomic<int> prog_strips{0}, prog_total{0};
 };
 
@@ -491,6 +492,7 @@ int mi355sw_stream_begin(mi355sw_handle* h, const mi355sw_partition* part, const
     a.strips_done_host = getenv("MI355SW_NOHOST") ? nullptr : h->h_pinned + 0;
     a.first_col_ready = (need_first_col && p->stream_first_column) ? h->h_pinned + 16 : nullptr;
     __atomic_store_n(&h->h_pinned[32], 0, __ATOMIC_RELEASE);
+    h->abort_strips = -1;
     a.host_abort = h->h_pinned + 32;
     a.gbest = ctrl + 52;
     // block pruning: packed SW kernel only (the int32 fallback and NW simply compute everything)
@@ -674,6 +676,10 @@ int mi355sw_stream_abort(mi355sw_handle* h) {
     if (!h || !h->active) return MI355SW_ESTATE;
     // a store into pinned memory the kernel polls with system scope: a copy, whatever its stream, may be held
     // back until the persistent kernel has left the queue it was mapped to -- and then stops nothing
+    if (h->abort_strips < 0) {
+        const int done = __atomic_load_n(&h->h_pinned[0], __ATOMIC_ACQUIRE);
+        h->abort_strips = std::min(h->strips, done + h->waves);
+    }
     __atomic_store_n(&h->h_pinned[32], 1, __ATOMIC_RELEASE);
     // unblock strips waiting for first-column rows that will never come
     __atomic_store_n(&h->h_pinned[16], h->m, __ATOMIC_RELEASE);
@@ -786,7 +792,9 @@ int mi355sw_stream_end(mi355sw_handle* h, mi355sw_score* best, int32_t* n_specia
     h->final_best = b;
     if (best) *best = b;
     if (n_special_rows) *n_special_rows = h->n_special;
-    const int done_strips = aborted ? ctrl[48] : h->strips;
+    // after a host stop the strips claimed later were skipped (they still count in ctrl[48]): an upper bound of
+    // what was computed is what was complete or in flight at that moment
+    const int done_strips = (aborted && h->abort_strips >= 0) ? h->abort_strips : (aborted ? ctrl[48] : h->strips);
     h->stats.processed_cells = (int64_t) std::min<long long>((long long) done_strips * h->SH, h->m) * h->n;
     {
         unsigned long long slabs = 0;
@@ -899,12 +907,17 @@ int mi355sw_align_partition(mi355sw_handle* h, const mi355sw_partition* part, co
     std::vector<mi355sw_cell> buf((size_t) std::max(SH, 1 << 16));
     int fed = 0, col_sent = 0, special_sent = 0;
     bool stopped = false, overflow = false;
+    int stop_rows = 0;                    // rows that were complete (and dispatched) when the manager said stop
     std::vector<mi355sw_cell> rowbuf;
     // first-column cells needed later for the leading cell of special/last rows
     std::vector<mi355sw_cell> fc_cells;   // fc_cells[k] = first column cell of DP row (k+1)*SH (or m)
     for (;;) {
         // feed the first column in strip-sized chunks (AbstractDiagonalAligner::loadFirstColumn :433-456)
-        if (orig_col_type != MI355SW_INIT_WITH_ZEROES) {
+        // (nothing more is fed once the manager has said stop: AbstractDiagonalAligner leaves its iteration loop at the
+        //  first mustContinue() == false, M/libmasa/aligners/AbstractDiagonalAligner.cpp:64; special rows above the
+        //  rows already dispatched are still handed over -- the reference flushes them before the column of the same
+        //  iteration, :286-372 -- rows below are void and stay here)
+        if (orig_col_type != MI355SW_INIT_WITH_ZEROES && !stopped) {
             int budget = 64;   // chunks per poll round, keeps the stream ahead without starving dispatches
             while (fed < m && budget-- > 0) {
                 const int len = std::min(SH, m - fed);
@@ -926,9 +939,9 @@ int mi355sw_align_partition(mi355sw_handle* h, const mi355sw_partition* part, co
         // special rows that are complete (AbstractDiagonalAligner::flushSpecialRows :286-317)
         // (reads of device-resident rows go through the copy stream: only once nothing more has to be
         //  fed, so that a copy delayed by the running kernel can never starve the kernel of its column)
-        while (special_sent < h->n_special && (fin || fed >= m || orig_col_type == MI355SW_INIT_WITH_ZEROES)) {
+        while ((!stopped || fin) && special_sent < h->n_special && (fin || fed >= m || orig_col_type == MI355SW_INIT_WITH_ZEROES)) {
             const int dp_row = (special_sent + 1) * h->special_interval_strips * SH;
-            if (dp_row > rows_done) break;
+            if (dp_row > (stopped ? stop_rows : rows_done)) break;
             mi355sw_cell c;
             if (orig_col_type == MI355SW_INIT_WITH_ZEROES) { c.h = 0; }
             else c = fc_cells[(size_t) dp_row / SH - 1];
@@ -947,10 +960,10 @@ int mi355sw_align_partition(mi355sw_handle* h, const mi355sw_partition* part, co
                 if ((rc = mi355sw_stream_read_column(h, col_sent, buf.data(), len))) { mi355sw_stream_abort(h); mi355sw_stream_end(h, nullptr, nullptr); return rc; }
                 mg->dispatch_column(user, part->j1, buf.data(), len);
                 col_sent += len;
-                if (mg->must_continue && !mg->must_continue(user)) stopped = true;
+                if (mg->must_continue && !mg->must_continue(user)) { stopped = true; stop_rows = col_sent; }
             }
         }
-        if (!stopped && mg->must_continue && !mg->must_continue(user)) stopped = true;
+        if (!stopped && mg->must_continue && !mg->must_continue(user)) { stopped = true; stop_rows = sp.want_last_column ? col_sent : rows_done; }
         if (stopped && !fin) { mi355sw_stream_abort(h); }
         if (fin && (stopped || (rows_done >= m && special_sent >= h->n_special && (!sp.want_last_column || col_sent >= m)))) break;
         if (fin && rows_done < m) break;   // aborted kernel

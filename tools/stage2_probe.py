@@ -9,12 +9,16 @@ pkg = g.load_package()
 from masa_cudalign_amd.manager import Stage1Manager, ArrayCellsReader, AT_SEQUENCE_1_AND_2
 
 m, n, stop_rows = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
+interval = int(sys.argv[4]) if len(sys.argv) > 4 else 0
 s0, s1 = pkg.seqgen.related_pair(m, n, cfg=9)
 INF = pkg.engine.INF
 col = np.zeros((m + 1, 2), dtype=np.int32); col[:, 0] = -2 * np.arange(m + 1) - 3; col[0, 0] = 0; col[:, 1] = -INF
 row = np.zeros((n + 1, 2), dtype=np.int32); row[:, 0] = -2 * np.arange(n + 1) - 3; row[0, 0] = 0; row[:, 1] = -INF
 
 class Mgr(Stage1Manager):
+    nrows = 0
+    def dispatchRow(self, i, buf, length):
+        self.nrows += 1
     def dispatchColumn(self, j, buf, length):
         self.last_column_pos += length
         if self.last_column_pos >= stop_rows:
@@ -24,12 +28,12 @@ al = pkg.MI355Aligner(device=0)
 al.setSequences(s0, s1)
 part = pkg.Partition(0, 0, m, n)
 for rep in range(3):
-    mg = Mgr(part, alignment_start=AT_SEQUENCE_1_AND_2, alignment_end=AT_SEQUENCE_1_AND_2, keep_last_column=True,
+    mg = Mgr(part, alignment_start=AT_SEQUENCE_1_AND_2, alignment_end=AT_SEQUENCE_1_AND_2, keep_last_column=True, special_row_interval=interval,
              first_row_reader=ArrayCellsReader(row), first_column_reader=ArrayCellsReader(col))
     t0 = time.time()
     al.alignPartition(part, mg)
     dt = time.time() - t0
     st = al.getStatistics()
-    print("m=%d n=%d stop_after=%d: wall %.1f ms kernel %.1f ms strips=%d strip_rows=%d waves=%d last-col rows seen %d" % (
-        m, n, stop_rows, dt * 1e3, st["kernel_ms"], st["strips"], st["strip_rows"], st["waves"], mg.last_column_pos), flush=True)
+    print("m=%d n=%d stop_after=%d: wall %.1f ms kernel %.1f ms strips=%d strip_rows=%d waves=%d last-col rows seen %d, row dispatches %d" % (
+        m, n, stop_rows, dt * 1e3, st["kernel_ms"], st["strips"], st["strip_rows"], st["waves"], mg.last_column_pos, mg.nrows), flush=True)
 al.close()
