@@ -377,7 +377,7 @@ int mi355sw_stream_begin(mi355sw_handle* h, const mi355sw_partition* part, const
     h->two_phase = h->use16 && p->track_best && (m >= (32 << 20) || getenv("MI355SW_TWO_PHASE"));
     h->ckpt_interval = 0; h->n_ckpt = 0; h->ckpt_pitch = h->special_pitch;
     if (h->two_phase) {
-        const int64_t budget = h->cfg.max_special_bytes > 0 ? h->cfg.max_special_bytes : (8LL << 30);
+        const int64_t budget = h->cfg.max_special_bytes > 0 ? h->cfg.max_special_bytes : (8LL << 30);   // checkpoints: 64 rows at most
         long long max_ck = budget / 2 / (long long) (sizeof(int2) * h->ckpt_pitch);
         if (max_ck > 64) max_ck = 64;
         if (max_ck < 1) max_ck = 1;
@@ -403,7 +403,13 @@ int mi355sw_stream_begin(mi355sw_handle* h, const mi355sw_partition* part, const
     if (p->want_last_row && (rc = ensure(h, h->d_last_row, sizeof(int2) * ((size_t) n + 64)))) return rc;
     if (h->n_special > 0) {
         const size_t bytes = sizeof(int2) * (size_t) h->special_pitch * h->n_special;
-        const int64_t budget = h->cfg.max_special_bytes > 0 ? h->cfg.max_special_bytes : (8LL << 30);
+        // default: 60 % of the HBM that is free right now (288 GB per MI355X: C3's 69 rows of 368 MB are 25 GB)
+        int64_t budget = h->cfg.max_special_bytes;
+        if (budget <= 0) {
+            size_t free_b = 0, total_b = 0;
+            budget = (hipMemGetInfo(&free_b, &total_b) == hipSuccess) ? (int64_t) ((double) free_b * 0.6) : (8LL << 30);
+            budget += (int64_t) h->d_special.cap;        // what this handle already holds for the purpose is reusable
+        }
         if ((int64_t) bytes > budget)
             FAIL(h, MI355SW_ENOMEM, "%d special rows need %zu bytes > budget %lld", h->n_special, bytes,
                  (long long) budget);
