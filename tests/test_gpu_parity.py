@@ -455,3 +455,56 @@ def test_randomised_differential_against_oracle(pkg, oracle, k):
             assert np.array_equal(mg.lastColumn(), ref["last_col"])
     finally:
         al.close()
+
+
+def test_stop_like_stage2_goal_found(pkg, oracle):
+    """The stage-2 call shape (M/stage2/sw_stage2.cpp:387-441): a tall, narrow NW partition with custom borders whose
+    manager says stop once the goal showed up in the last column.  What was dispatched before the stop is exact,
+    special rows below the stop are not handed over, nothing more is asked from the first-column stream, and the
+    engine does not sweep the rest of the partition."""
+    from masa_cudalign_amd.manager import ArrayCellsReader
+    m, n, stop_after = 4000000, 2000, 20000
+    s0, s1 = pkg.seqgen.related_pair(m, n, cfg=91)
+    INF = pkg.engine.INF
+    col = np.zeros((m + 1, 2), dtype=np.int32); col[:, 0] = -2 * np.arange(m + 1) - 3; col[0, 0] = 0; col[:, 1] = -INF
+    row = np.zeros((n + 1, 2), dtype=np.int32); row[:, 0] = -2 * np.arange(n + 1) - 3; row[0, 0] = 0; row[:, 1] = -INF
+
+    class CountingReader(ArrayCellsReader):
+        def read(self, buf, length):
+            self.asked = getattr(self, "asked", 0) + length
+            return ArrayCellsReader.read(self, buf, length)
+
+    class Mgr(pkg.Stage1Manager):
+        def dispatchColumn(self, j, buf, length):
+            pkg.Stage1Manager.dispatchColumn(self, j, buf, length)
+            if self.last_column_pos >= stop_after:
+                self.active = False                      # AlignerManager::stopAligner, AlignerManager.cpp:357-370
+
+    creader = CountingReader(col)
+    al = pkg.MI355Aligner(device=0)
+    try:
+        al.setSequences(s0, s1)
+        part = pkg.Partition(0, 0, m, n)
+        mg = Mgr(part, alignment_start=pkg.AT_SEQUENCE_1_AND_2, alignment_end=pkg.AT_SEQUENCE_1_AND_2,
+                 keep_last_column=True, special_row_interval=8192,
+                 first_row_reader=ArrayCellsReader(row), first_column_reader=creader)
+        al.alignPartition(part, mg)
+        st = al.getStatistics()
+    finally:
+        al.close()
+    got = mg.lastColumn()                    # corner cell + the rows dispatched before the stop
+    seen = got.shape[0] - 1
+    assert stop_after <= seen < stop_after + 4 * st["strip_rows"]
+    # rows 0..seen of the matrix do not depend on anything below them
+    ref = oracle.stage1(s0[:seen], s1, recurrence=oracle.NEEDLEMAN_WUNSCH, first_row_type=oracle.INIT_WITH_GAPS,
+                        first_col_type=oracle.INIT_WITH_GAPS, best_mode=oracle.BEST_LAST_CELL,
+                        block_h=st["strip_rows"], block_w=1 << 20, want_last_col=True,
+                        special_row_interval=st["strip_rows"])
+    assert np.array_equal(got, ref["last_col"])
+    rows = sorted(mg.special_rows)
+    assert rows and all(r <= seen for r in rows)
+    want = dict(zip(ref["special_row_ids"], ref["special_rows"]))
+    for r in rows:
+        assert np.array_equal(mg.specialRow(r), want[r]), r
+    assert creader.asked < m // 2                       # the first-column stream was left alone after the stop
+    assert st["processed_cells"] < 0.6 * m * n          # and much of the partition was never computed
