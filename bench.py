@@ -74,6 +74,21 @@ def cpu_baseline(pkg, seconds_budget=20.0):
             "sample": "%dx%d unrelated SW stage-1, oracle/sw_oracle.c, best=%s" % (side, side, list(r["best"]))}
 
 
+def cpu_baseline_mt(pkg):
+    """the same recurrence on every host core: the repo's C restatement of CPUBlockProcessor (oracle/sw_oracle.c,
+    1024 x 1024 blocks on an anti-diagonal wavefront of threads) -- extra information next to the single-thread
+    reference figure, not a replacement for it"""
+    oracle = graft.load_oracle()
+    cores = min(64, os.cpu_count() or 1)
+    side = 120000
+    s0, s1 = pkg.seqgen.unrelated_pair(side, side, cfg=1)
+    t0 = time.time()
+    r = oracle.stage1(s0, s1, threads=cores)
+    dt = time.time() - t0
+    return {"value": side * side / dt / 1e9, "unit": "GCUPS", "cores": cores, "kind": "port",
+            "sample": "%dx%d unrelated SW stage-1, oracle/sw_oracle.c on %d threads, best=%s" % (side, side, cores, list(r["best"]))}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -220,6 +235,7 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pkg)
+            out["cpu_baseline_all_cores"] = cpu_baseline_mt(pkg)
         print(json.dumps(out), flush=True)
     al.close()
     if world > 1:
