@@ -180,6 +180,11 @@ int mi355sw_create(const mi355sw_config* config, mi355sw_handle** out) {
     // sit behind it forever.  The kernel stream therefore lives alone in the high-priority pool.
     int prio_lo = 0, prio_hi = 0;
     (void) hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+    // MI355SW_STREAM_PRIO=low|normal: experiments with two engines in one process (tools/concurrency_probe.py)
+    if (const char* sp = getenv("MI355SW_STREAM_PRIO")) {
+        if (!strcmp(sp, "low")) prio_hi = prio_lo;
+        else if (!strcmp(sp, "normal")) prio_hi = (prio_lo + prio_hi) / 2;
+    }
     if (hipStreamCreateWithPriority(&h->stream, hipStreamNonBlocking, prio_hi) != hipSuccess ||
         hipStreamCreateWithFlags(&h->copy, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess ||
