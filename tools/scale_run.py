@@ -109,6 +109,29 @@ def case_c3(out, m=48000000, n=46000000):
     assert out["same_best"] and out["rows_lower_bound"] and out["row_max_equal_above_best"], out
 
 
+def case_nw_tall(out, m=249000000, n=500000):
+    """C5's height (249 M rows, beyond the reference's 134 M texture limit) as a global NW with gap-initialised
+    borders: the packed kernel (window follows the scores down to -5e8) and the int32 kernel must agree on
+    H[m][n] and on the whole last row"""
+    from masa_cudalign_amd.engine import NEEDLEMAN_WUNSCH, INIT_WITH_GAPS
+    s0, s1 = pkg.seqgen.related_pair(m, n, cfg=15)
+    part = pkg.Partition(0, 0, m, n)
+    res = {}
+    for name, force in (("pk16", False), ("int32", True)):
+        al = pkg.MI355Aligner(device=0)
+        al.setSequences(s0, s1)
+        def last_row(al):
+            row = al.streamReadLastRow()
+            return {"H_last_cell": int(row[-1, 0]), "sha256": hashlib.sha256(np.ascontiguousarray(row).tobytes()).hexdigest()}
+        r = run(al, part, before_end=last_row, recurrence_type=NEEDLEMAN_WUNSCH, first_row_init_type=INIT_WITH_GAPS,
+                first_column_init_type=INIT_WITH_GAPS, want_last_row=True, track_best=False, force_int32=force)
+        al.close()
+        res[name] = r
+    out.update(res)
+    out["agree"] = res["pk16"]["rows"] == res["int32"]["rows"]
+    assert out["agree"], out
+
+
 def case_c2x(out, m=3000000, n=3000000):
     s0, s1 = pkg.seqgen.unrelated_pair(m, n, cfg=2)
     al = pkg.MI355Aligner(device=0)
@@ -135,6 +158,10 @@ if __name__ == "__main__":
         case_unrelated(1000000, 228000000, 12, out)
     elif case == "tallsmall":
         case_unrelated(40000000, 100000, 11, out)
+    elif case == "nwtall":
+        case_nw_tall(out)
+    elif case == "nwtallsmall":
+        case_nw_tall(out, 40000000, 50000)
     elif case == "c2x":
         case_c2x(out)
     else:
