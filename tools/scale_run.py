@@ -132,6 +132,47 @@ def case_nw_tall(out, m=249000000, n=500000):
     assert out["agree"], out
 
 
+def case_c4chain(out, m=59000000, w=8000000):
+    """C4's height (59 M rows) as a chain of two column bands of w columns through the multi-GPU band driver
+    (masa-cudalign_amd/bands.py, the code bench.py --gpus N runs), one band after the other on this one GPU with the
+    boundary column handed over in 32 k-row segments; the chain must report what ONE partition of 2w columns reports"""
+    import collections
+    from masa_cudalign_amd.bands import BandRunner, canonical_best
+
+    class Relay:                     # stands in for torch.distributed: rank 0's sends are rank 1's receives
+        def __init__(self):
+            self.q = collections.deque()
+        def send(self, t, dst):
+            self.q.append(t.clone())
+        def recv(self, t, src):
+            while not self.q:
+                time.sleep(0.001)
+            t.copy_(self.q.popleft())
+
+    s0, s1 = pkg.seqgen.unrelated_pair(m, 2 * w, cfg=4)
+    al = pkg.MI355Aligner(device=0)
+    al.setSequences(s0, s1)
+    relay = Relay()
+    res = []
+    for rank in (0, 1):
+        t0 = time.time()
+        b = BandRunner(al, dist=relay, rank=rank, world=2, device=None, segment_rows=1 << 15).run(m, rank * w, (rank + 1) * w)
+        st = al.getStatistics()
+        res.append({"band": rank, "best": list(b), "wall_s": time.time() - t0, "kernel_ms": st["kernel_ms"],
+                    "gcups": m * w / st["kernel_ms"] / 1e6, "strip_rows": st["strip_rows"]})
+        print(json.dumps(res[-1]), flush=True)
+    t0 = time.time()
+    whole = BandRunner(al, dist=None, rank=0, world=1).run(m, 0, 2 * w)
+    st = al.getStatistics()
+    out["bands"] = res
+    out["whole"] = {"best": list(whole), "wall_s": time.time() - t0, "kernel_ms": st["kernel_ms"], "gcups": m * 2 * w / st["kernel_ms"] / 1e6}
+    out["chain_best"] = list(canonical_best([tuple(r["best"]) for r in res]))
+    out["agree"] = out["chain_best"] == out["whole"]["best"]
+    al.close()
+    out["check"] = window_check(s0, s1, out["chain_best"])
+    assert out["agree"] and out["check"]["ok"], out
+
+
 def case_c2x(out, m=3000000, n=3000000):
     s0, s1 = pkg.seqgen.unrelated_pair(m, n, cfg=2)
     al = pkg.MI355Aligner(device=0)
@@ -162,6 +203,10 @@ if __name__ == "__main__":
         case_nw_tall(out)
     elif case == "nwtallsmall":
         case_nw_tall(out, 40000000, 50000)
+    elif case == "c4chain":
+        case_c4chain(out)
+    elif case == "c4chainsmall":
+        case_c4chain(out, 3000000, 400000)
     elif case == "c2x":
         case_c2x(out)
     else:
