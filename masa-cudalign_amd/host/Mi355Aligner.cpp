@@ -17,7 +17,8 @@ Mi355Aligner::Mi355Aligner(int device, int rowsPerLane, int waves) : handle(NULL
     score_params.mismatch = sp.mismatch;
     score_params.gap_open = sp.gap_open;
     score_params.gap_ext = sp.gap_ext;
-    params = new BlockAlignerParameters();
+    params = new Mi355AlignerParameters();
+    if (device >= 0) params->setGPU(device);
     setForkCount(1);
     clearStatistics();
     progress[0] = 0;
@@ -69,7 +70,23 @@ const score_params_t* Mi355Aligner::getScoreParameters() { return &score_params;
 IAlignerParameters* Mi355Aligner::getParameters() { return params; }
 
 void Mi355Aligner::initialize() {
-    if (!handle) check(mi355sw_create(&config, &handle), "mi355sw_create");
+    if (handle) return;
+    // GPU selection as in CUDAligner::initialize (X/CUDAligner.cpp:137-150): a forked instance takes the GPU of its
+    // fork id (wrapping around), otherwise --gpu, otherwise the fastest device
+    if (params->getForkId() != NOT_FORKED_INSTANCE) {
+        const int gpus = mi355sw_device_count();
+        int id = params->getForkId();
+        if (gpus > 0 && id >= gpus) {
+            fprintf(stderr, "INFO: Wrapping gpu ID (%d -> %d). (max.: %d).\n", id, id % gpus, gpus);
+            id %= gpus;
+        }
+        params->setGPU(id);
+    }
+    if (params->getGPU() == MI355_DETECT_FASTEST_GPU) params->setGPU(Mi355AlignerParameters::fastestGPU());
+    config.device = params->getGPU();
+    if (params->getWaves() > 0) config.waves = params->getWaves();
+    if (params->getStripRows() > 0) config.rows_per_lane = params->getStripRows() / 64;
+    check(mi355sw_create(&config, &handle), "mi355sw_create");
 }
 
 void Mi355Aligner::finalize() {

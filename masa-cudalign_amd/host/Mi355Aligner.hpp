@@ -9,7 +9,7 @@
 
 #include "libmasa/libmasa.hpp"
 #include "libmasa/aligners/AbstractAligner.hpp"
-#include "libmasa/parameters/BlockAlignerParameters.hpp"
+#include "Mi355AlignerParameters.hpp"
 
 #include "mi355sw.h"
 
@@ -59,7 +59,7 @@ private:
     mi355sw_handle* handle;
     mi355sw_config config;
     score_params_t score_params;
-    BlockAlignerParameters* params;
+    Mi355AlignerParameters* params;
     mutable char progress[256];
     long long statCells;
     double statKernelMs;

@@ -1,0 +1,31 @@
+// Command-line parameters of the MI355X extension: the counterpart of X/CUDAlignerParameters.{hpp,cpp}
+// (--gpu, --list-gpus, --blocks) for an engine whose unit of parallelism is a strip wavefront.
+// MASA-Core hands every option it does not know to IAlignerParameters::processArgument
+// (M/libmasa/IAlignerParameter.hpp, M/libmasa/parameters/AbstractAlignerParameters.cpp:58-67).
+#ifndef MI355ALIGNERPARAMETERS_HPP_
+#define MI355ALIGNERPARAMETERS_HPP_
+
+#include "libmasa/parameters/AbstractAlignerParameters.hpp"
+
+#define MI355_DETECT_FASTEST_GPU (-1)     /* X/CUDAlignerParameters.hpp: DETECT_FASTEST_GPU */
+#define MI355_MAX_WAVES 4096
+
+class Mi355AlignerParameters : public AbstractAlignerParameters {
+public:
+    Mi355AlignerParameters();
+    virtual ~Mi355AlignerParameters();
+    virtual void printUsage() const;
+    virtual int processArgument(int argc, char** argv);
+
+    int getGPU() const { return gpu; }
+    void setGPU(int g) { gpu = g; }
+    int getWaves() const { return waves; }            /* --blocks: strip wavefronts per launch, 0 = one per SIMD */
+    int getStripRows() const { return stripRows; }    /* --strip-rows: 256..2048, 0 = cost model */
+    static void printGPUDevices(FILE* file);          /* --list-gpus (X/cuda_util.cpp:191-230) */
+    static int fastestGPU();                          /* X/cuda_util.cpp:238-287: largest CUs x clock */
+
+private:
+    int gpu, waves, stripRows;
+};
+
+#endif

@@ -46,7 +46,7 @@ REPO="$(dirname "$HERE")"
 LIB="$REPO/masa-cudalign_amd/libmi355sw.so"
 if [ -f "$LIB" ]; then
     $CXX $FLAGS -DUSE_MI355_ALIGNER -I"$REPO/include" -I"$REPO/masa-cudalign_amd/host" \
-        "$HERE/ref_driver.cpp" "$REPO/masa-cudalign_amd/host/Mi355Aligner.cpp" "$OBJ"/*.o \
+        "$HERE/ref_driver.cpp" "$REPO/masa-cudalign_amd/host/Mi355Aligner.cpp" "$REPO/masa-cudalign_amd/host/Mi355AlignerParameters.cpp" "$OBJ"/*.o \
         -L"$REPO/masa-cudalign_amd" -lmi355sw -Wl,-rpath,'$ORIGIN/../../masa-cudalign_amd' -lpthread \
         -o "$OUT/masa_mi355"
     echo "built $OUT/masa_mi355"

@@ -245,6 +245,7 @@ int main(int argc, char** argv) {
     int max_alignments = 1;
     std::string flush_url, load_url;
     std::vector<const char*> files;
+    std::vector<char*> extension_args;
 
     for (int a = 1; a < argc; a++) {
         const char* s = argv[a];
@@ -261,16 +262,25 @@ int main(int argc, char** argv) {
         else if (!strncmp(s, "--flush-column=", 15)) { flush_url = s + 15; pruning = false; }
         else if (!strncmp(s, "--load-column=", 14)) { load_url = s + 14; pruning = false; }
         else if (!strncmp(s, "--max-alignments=", 17)) max_alignments = atoi(s + 17);
-        else if (s[0] == '-') { fprintf(stderr, "unknown option %s\n", s); return 2; }
+        else if (s[0] == '-') extension_args.push_back(argv[a]);    /* libmasa.cpp hands unknown options to the extension */
         else files.push_back(s);
     }
     if (files.size() != 2) { fprintf(stderr, "need two fasta files\n"); return 2; }
 
 #ifdef USE_MI355_ALIGNER
-    Mi355Aligner* aligner = new Mi355Aligner(0, 0, 0);
+    Mi355Aligner* aligner = new Mi355Aligner(-1, 0, 0);
     (void) bh; (void) bw;
+    for (size_t k = 0; k < extension_args.size(); k++) {
+        char* av[3] = {argv[0], extension_args[k], NULL};
+        optind = 2;                       /* AbstractAlignerParameters::callGetOpt re-reads argv[optind - 1] */
+        if (aligner->getParameters()->processArgument(2, av) != 0) {
+            fprintf(stderr, "option %s: %s\n", extension_args[k], aligner->getParameters()->getLastError());
+            return 2;
+        }
+    }
 #else
     SerialBlockAligner* aligner = new SerialBlockAligner(bh, bw);
+    if (!extension_args.empty()) { fprintf(stderr, "unknown option %s\n", extension_args[0]); return 2; }
 #endif
 
     /* libmasa.cpp:765-806 defaults */

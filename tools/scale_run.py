@@ -197,6 +197,8 @@ if __name__ == "__main__":
         case_unrelated(228000000, 1000000, 11, out)
     elif case == "wide":
         case_unrelated(1000000, 228000000, 12, out)
+    elif case == "tallband":          # 1/14 of the 228 M x 228 M north-star matrix: its full height, one band of its width
+        case_unrelated(228000000, 16000000, 13, out)
     elif case == "tallsmall":
         case_unrelated(40000000, 100000, 11, out)
     elif case == "nwtall":
