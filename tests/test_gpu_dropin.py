@@ -98,4 +98,3 @@ def test_extension_command_line_options(pkg, oracle):
     args = [a for a in case["args"] if not a.startswith("--block=")]
     res = _run(pkg, oracle, case["seq"], args + ["--gpu=0", "--blocks=64", "--strip-rows=512"])
     assert list(res["best"]) == case["best"]
-    assert "strip rows 512" in res["log"] or True       # geometry is reported by the engine statistics when printed
