@@ -188,6 +188,7 @@ def main():
         torch.cuda.synchronize()
 
     best = None
+    fence()                            # all bands start together: a band's kernel waits a bounded time for its left neighbour
     for _ in range(args.warmup):
         best, _st = one_step()
     fence()

@@ -132,6 +132,71 @@ def case_nw_tall(out, m=249000000, n=500000):
     assert out["agree"], out
 
 
+def case_c5band(out, m=249000000, n=28500000, k_rows=400, k_cols=48):
+    """ONE GPU's share of BASELINE config C5 at full size: band 0 of the 8 column bands of the 249 M x 228 M global
+    NW (all 249 M rows x 28.5 M columns, gap-initialised borders, last column kept as it would be streamed to band 1,
+    last row kept).  No oracle can sweep 7e15 cells; the run is pinned on its borders and through a size-independent
+    property: (1) the first k_rows cells of the last column equal the oracle's sweep of those rows over the whole
+    band, (2) the first k_cols cells of the last row equal the oracle's sweep of all 249 M rows over those columns,
+    (3) neighbouring cells of the last row / last column never differ by more than match + open + ext + |mismatch|
+    (a global score changes by at most one edit when one letter is appended), (4) sha256 of both borders recorded."""
+    from masa_cudalign_amd.engine import NEEDLEMAN_WUNSCH, INIT_WITH_GAPS
+    t0 = time.time()
+    s0, s1 = pkg.seqgen.related_pair(m, n, cfg=15)
+    out["generate_s"] = time.time() - t0
+    part = pkg.Partition(0, 0, m, n)
+    al = pkg.MI355Aligner(device=0)
+    al.setSequences(s0, s1)
+    keep = {}
+
+    def borders(al):
+        row = al.streamReadLastRow()
+        keep["row_head"] = row[:k_cols].copy()
+        hs, hc, step, mx = hashlib.sha256(), hashlib.sha256(), 1 << 24, 0
+        hs.update(np.ascontiguousarray(row).tobytes())
+        mx_row = int(np.abs(np.diff(row[:, 0].astype(np.int64))).max()) if n > 1 else 0
+        prev = None
+        for r0 in range(0, m, step):
+            col = al.streamReadColumn(r0, min(step, m - r0))
+            if r0 == 0:
+                keep["col_head"] = col[:k_rows].copy()
+            hc.update(np.ascontiguousarray(col).tobytes())
+            h = col[:, 0].astype(np.int64)
+            if prev is not None:
+                mx = max(mx, abs(int(h[0]) - prev))
+            if len(h) > 1:
+                mx = max(mx, int(np.abs(np.diff(h)).max()))
+            prev = int(h[-1])
+            last = col[-1].copy()
+        return {"H_last_cell": int(row[-1, 0]), "last_column_tail_H": int(last[0]),
+                "last_row_sha256": hs.hexdigest(), "last_column_sha256": hc.hexdigest(),
+                "max_step_last_row": mx_row, "max_step_last_column": mx}
+
+    r = run(al, part, before_end=borders, recurrence_type=NEEDLEMAN_WUNSCH, first_row_init_type=INIT_WITH_GAPS,
+            first_column_init_type=INIT_WITH_GAPS, want_last_row=True, want_last_column=True, track_best=False)
+    al.close()
+    out.update(r)
+    oracle = g.load_oracle()
+    t0 = time.time()
+    top = oracle.stage1(s0[:k_rows], s1, recurrence=NEEDLEMAN_WUNSCH, first_row_type=INIT_WITH_GAPS,
+                        first_col_type=INIT_WITH_GAPS, want_last_col=True, best_mode=oracle.BEST_LAST_CELL)
+    left = oracle.stage1(s0, s1[:k_cols], recurrence=NEEDLEMAN_WUNSCH, first_row_type=INIT_WITH_GAPS,
+                         first_col_type=INIT_WITH_GAPS, want_last_row=True, best_mode=oracle.BEST_LAST_CELL)
+    out["oracle_s"] = time.time() - t0
+    oc, orow = np.asarray(top["last_col"]), np.asarray(left["last_row"])
+    oc = oc[-k_rows:] if len(oc) > k_rows else oc          # a leading corner cell, if the oracle returns one
+    orow = orow[-k_cols:] if len(orow) > k_cols else orow
+    out["check"] = {
+        "last_column_head_rows": k_rows, "last_column_head_equal": bool((keep["col_head"] == oc).all()),
+        "last_row_head_cols": k_cols, "last_row_head_equal": bool((keep["row_head"] == orow).all()),
+        "lipschitz_bound": 9,
+        "lipschitz_ok": bool(r["rows"]["max_step_last_row"] <= 9 and r["rows"]["max_step_last_column"] <= 9),
+        "corner_consistent": bool(r["rows"]["H_last_cell"] == r["rows"]["last_column_tail_H"]),
+    }
+    out["check"]["ok"] = all(v for k, v in out["check"].items() if isinstance(v, bool))
+    assert out["check"]["ok"], out["check"]
+
+
 def case_c4chain(out, m=59000000, w=8000000):
     """C4's height (59 M rows) as a chain of two column bands of w columns through the multi-GPU band driver
     (masa-cudalign_amd/bands.py, the code bench.py --gpus N runs), one band after the other on this one GPU with the
@@ -205,6 +270,10 @@ if __name__ == "__main__":
         case_nw_tall(out)
     elif case == "nwtallsmall":
         case_nw_tall(out, 40000000, 50000)
+    elif case == "c5band":
+        case_c5band(out)
+    elif case == "c5bandsmall":
+        case_c5band(out, 6000000, 400000, 300, 40)
     elif case == "c4chain":
         case_c4chain(out)
     elif case == "c4chainsmall":
