@@ -12,6 +12,8 @@ score is an all_gather of one (score,i,j) triple reduced with BestScoreList's or
 The compute engine is injected (`engine_factory`) so that the N>1 plumbing can be exercised on CPU
 with a stand-in; the product engine is MI355Aligner (HIP, no CPU fallback).
 """
+import os
+import sys
 import threading
 import time
 
@@ -124,7 +126,28 @@ class BandRunner:
             rx = threading.Thread(target=receiver, daemon=True)
             rx.start()
         send_q = 0
+        # a chain that stands still says where: one line per 10 s without progress on this band (rows completed,
+        # segments sent), one per second with MI355SW_BAND_DEBUG=1; after MI355SW_BAND_STALL_S seconds (default
+        # 900) without progress the band gives up instead of hanging its neighbours for ever
+        debug = os.environ.get("MI355SW_BAND_DEBUG") == "1"
+        stall_abort = float(os.environ.get("MI355SW_BAND_STALL_S", "900"))
+        t_dbg = t_prog = time.time()
+        seen = (-1, -1)
         while True:
+            now = time.time()
+            if now - t_dbg >= (1.0 if debug else 10.0):
+                t_dbg = now
+                with lock:
+                    rd, fn = eng.streamPoll()
+                if (rd, send_q) != seen:
+                    seen, t_prog = (rd, send_q), now
+                if debug or now - t_prog >= 10.0:
+                    sys.stderr.write("[band %d/%d] rows_done=%d/%d finished=%d segments_sent=%d/%d no progress for %.0f s\n"
+                                     % (self.rank, self.world, rd, m, int(fn), send_q, nseg, now - t_prog))
+                    sys.stderr.flush()
+                if now - t_prog >= stall_abort:
+                    errors.append(RuntimeError("band %d/%d: no progress for %.0f s (rows_done=%d/%d, segments_sent=%d/%d)"
+                                               % (self.rank, self.world, now - t_prog, rd, m, send_q, nseg)))
             if errors:
                 with lock:
                     eng.streamAbort()

@@ -1,4 +1,4 @@
-"""CPU, world_size 2 (gloo): the column-band driver (masa-cudalign_amd/bands.py) streams the boundary
+"""CPU, world_size 2, 3 and 4 (gloo): the column-band driver (masa-cudalign_amd/bands.py) streams the boundary
 column between ranks while both bands are running, and the reduced best equals the single-band answer.
 The compute engine is a test double built on the oracle (the product engine needs a GPU)."""
 import os
@@ -106,8 +106,9 @@ def _worker(rank, world, port, m, n, q):
 
 
 @pytest.mark.timeout(300)
-def test_two_bands_over_gloo(pkg, oracle):
-    m, n, world = 1500, 1800, 2
+@pytest.mark.parametrize("world", [2, 3, 4])       # 3 and 4: middle bands receive and send at the same time
+def test_bands_over_gloo(pkg, oracle, world):
+    m, n = 1500, 1800
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
