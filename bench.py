@@ -114,9 +114,6 @@ def main():
     # MI355SW_BENCH_REHEARSAL=1: run the N>1 path on a ONE-GPU box (every rank on cuda:0, gloo instead of RCCL for
     # the collectives, --waves small enough for all ranks' strip kernels to be resident together).  It exercises
     # the band driver, the column transport and the result line; its numbers mean nothing.
-    # Up to 3 ranks run reliably that way; with 4 processes on one GPU the left-most band's kernel is sometimes never
-    # scheduled next to the three that wait for it (all four print "no progress" lines: bands.py) -- a limit of
-    # sharing one GPU between processes, not of the chain: on a node every band has its own GPU.
     rehearse = os.environ.get("MI355SW_BENCH_REHEARSAL") == "1"
     if rehearse:
         local_rank = 0

@@ -383,7 +383,22 @@ __device__ __attribute__((noinline)) int claim_strip(const KernelArgs* ap, const
     const UniformArgs a = uniform_args(ap);
     int s = 0;
     if (lane == 0) s = atomicAdd(a->ticket, 1);
-    return __builtin_amdgcn_readfirstlane(s);
+    s = __builtin_amdgcn_readfirstlane(s);
+    // Streamed first column (a band fed by another GPU): the strip function polls a counter in pinned HOST memory
+    // until its rows have arrived, a PCIe round trip per poll.  A strip cannot move before the strip above has
+    // produced its first columns anyway, so wait for that here first (device-scope poll): one or two wavefronts
+    // then poll the host at any time instead of every wavefront of the launch (with all of them polling, the
+    // neighbour band's stores to its pinned last column crawled: 48 s instead of 8.6 s per step when two bands
+    // shared one GPU's PCIe link).
+    if (a->first_col_ready != nullptr && s < a->num_strips) {
+        const int* prog_in = &a->progress[s];
+        int spins = 0;
+        while (poll_agent(prog_in) < 1 && poll_agent(a->abort_flag) == 0 && spins < (1 << 28)) {
+            __builtin_amdgcn_s_sleep(16);
+            spins++;
+        }
+    }
+    return s;
 }
 
 template <int R, bool SW, bool PROFILE, bool TRACK>
