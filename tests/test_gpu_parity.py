@@ -163,7 +163,8 @@ def test_process_block_seam(pkg, oracle, aligner):
         aligner.unsetSequences()
 
 
-def test_streamed_column_bands_on_one_gpu(pkg, oracle):
+@pytest.mark.parametrize("flags", [0, 2, 3])     # packed kernel, int32 profile kernel, int32 byte-compare kernel
+def test_streamed_column_bands_on_one_gpu(pkg, oracle, flags):
     """the 8-GPU chain emulated on one GPU: bands run one after the other, each fed with the previous
     band's last column through the streaming ABI; boundary columns and bests match the reference chain."""
     ch = G["chain"]
@@ -171,7 +172,7 @@ def test_streamed_column_bands_on_one_gpu(pkg, oracle):
     n, parts = len(s1), ch["parts"]
     from masa_cudalign_amd.bands import band_limits, canonical_best
     lim = band_limits(n, [1] * parts)
-    al = pkg.MI355Aligner(device=0)
+    al = pkg.MI355Aligner(device=0, flags=flags)
     try:
         al.setSequences(s0, s1)
         col, cands = None, []
