@@ -2,6 +2,7 @@
 import hashlib
 
 import numpy as np
+import pytest
 
 
 def test_initial_cells_reader_matches_oracle(pkg, oracle):
@@ -65,3 +66,33 @@ def test_stage1_manager_on_oracle_rows(pkg, oracle):
         ch = lr[1 + j:1 + min(j + 200, 900)]
         mg.dispatchRow(700, ch, len(ch))
     assert tuple(mg.getBestScore()) == tuple(r["best"])
+
+
+def test_band_loop_gives_up_on_a_stalled_band(pkg, monkeypatch):
+    """a band whose kernel never completes a row is reported and then aborted (bands.py stall reporter) instead of
+    hanging its neighbours: the engine is told to abort and the error names the band"""
+    from masa_cudalign_amd.bands import BandRunner
+
+    class StuckEngine:
+        aborted = ended = False
+
+        def streamBegin(self, part, **kw):
+            pass
+
+        def streamPoll(self):
+            return 0, False
+
+        def streamAbort(self):
+            self.aborted = True
+
+        def streamEnd(self):
+            self.ended = True
+            return (-1, -1, -pkg.INF), 0
+
+    monkeypatch.setenv("MI355SW_BAND_DEBUG", "1")
+    monkeypatch.setenv("MI355SW_BAND_STALL_S", "2")
+    eng = StuckEngine()
+    runner = BandRunner(eng, dist=None, rank=0, world=1)
+    with pytest.raises(RuntimeError, match="band 0/1: no progress"):
+        runner.run(1000, 0, 500)
+    assert eng.aborted and eng.ended
