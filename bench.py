@@ -30,7 +30,7 @@ HBM_PEAK_GBS = 8000.0                 # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 VALU_PEAK_WAVE_INSTR = 256 * 4 * 0.59e9
 # HBM-side traffic of one launch from the PMC passes (profiles/r01_pk16_hbm_pmc.json: FETCH_SIZE x2 gfx950
 # correction + WRITE_SIZE), keyed by (kernel, m, n, strip_rows); other configurations report null
-PMC_TRAFFIC_BYTES = {("pk16", 3000000, 3000000, 1536): 111997943552.0}
+PMC_TRAFFIC_BYTES = {("pk16", 3000000, 3000000, 1536): 112130775680.0}
 # VALU instructions per wave-step (SQ_INSTS_VALU / wave-steps; one step = strip_rows cells).  pk16/1536 is
 # measured (profiles/r01_pk16_sq_pmc.json: 128.5); the other packed heights scale its 9.65 per packed row
 # pair + 12 per step; int32 figures are from profiles/r01_int32_sq_pmc.json
