@@ -9,7 +9,9 @@ One "step" = one complete Stage-1 pass (score + canonical position) over the syn
 sequences already resident in HBM.
   N = 1 : BASELINE config C2, 3,000,000 x 3,000,000 unrelated random ACGT, local SW, score-only.
   N > 1 : weak scaling, per-GPU work fixed at 9e12 cells: (3,000,000*N) x 3,000,000, seq1 cut into N
-          column bands, boundary column streamed rank g -> g+1 over RCCL point-to-point (bands.py).
+          column bands, boundary column streamed rank g -> g+1 while all strip kernels run (bands.py): through
+          pinned zero-copy host columns + gloo by default, RCCL send/recv of device tensors with
+          MI355SW_BENCH_COMM=nccl; barrier, best-score all_gather and timing all_reduce go over RCCL.
 Rank 0 prints ONE JSON line.  GCUPS convention of the reference: cells = m*n (sw_stage1.cpp:440-448).
 """
 import argparse
