@@ -76,7 +76,7 @@ class BandRunner:
         return torch.empty((rows, 2), dtype=torch.int32, device=self.device if self.device is not None else "cpu")
 
     def run(self, m, j0, j1, recurrence=SMITH_WATERMAN, track_best=True, first_row_init_type=INIT_WITH_ZEROES,
-            first_col_init_type=INIT_WITH_ZEROES, poll_sleep=0.0005):
+            first_col_init_type=INIT_WITH_ZEROES, poll_sleep=0.0005, want_last_row=False, before_end=None):
         """seq1 of the engine must already hold the whole horizontal sequence (or at least [j0,j1))."""
         eng, dist = self.engine, self.dist
         first, last = self.rank == 0, self.rank == self.world - 1
@@ -85,7 +85,7 @@ class BandRunner:
         nseg = (m + seg - 1) // seg
         kw = dict(recurrence_type=recurrence, track_best=track_best,
                   first_row_init_type=first_row_init_type, first_row_start_offset=j0,
-                  want_last_column=not last,
+                  want_last_column=not last, want_last_row=want_last_row,
                   # block pruning: never when the matrix is split over processes (as the reference,
                   # libmasa.cpp:1318-1321); for a single band it is the caller's choice (self.prune_blocks)
                   prune_blocks=(self.prune_blocks and self.world == 1 and recurrence == SMITH_WATERMAN and track_best))
@@ -178,6 +178,8 @@ class BandRunner:
                 time.sleep(poll_sleep)
         if rx is not None:
             rx.join()
+        if before_end is not None:       # e.g. read this band's slice of the last row while the stream is open
+            before_end(eng)
         best, _ = eng.streamEnd()
         return best
 

@@ -124,3 +124,52 @@ def test_bands_over_gloo(pkg, oracle, world):
     want = (ref["best"][0] - 1, ref["best"][1] - 1, ref["best"][2])   # 0-based cell, as the engine reports
     for rank, best, gbest in res:
         assert gbest == want, (rank, best, gbest, want)
+
+
+def _worker_nw(rank, world, port, m, n, q):
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as graft
+    pkg = graft.load_package()
+    oracle = graft.load_oracle()
+    from masa_cudalign_amd.bands import BandRunner, band_limits
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        s0, s1 = pkg.seqgen.related_pair(m, n, cfg=44)
+        lim = band_limits(n, [1] * world)
+        eng = OracleStreamEngine(oracle, s0, s1, seg=128)
+        runner = BandRunner(eng, dist=dist, rank=rank, world=world, device=None, segment_rows=256)
+        runner.run(m, lim[rank], lim[rank + 1], recurrence=oracle.NEEDLEMAN_WUNSCH, track_best=False,
+                   first_row_init_type=oracle.INIT_WITH_GAPS, first_col_init_type=oracle.INIT_WITH_GAPS)
+        q.put((rank, eng.last_col.copy()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_global_nw_bands_over_gloo(pkg, oracle):
+    """C5's recurrence through the band driver: global NW with gap-initialised borders over 3 bands -- every band's
+    last column (corner cells, first-row offsets of the inner bands) equals that column of the one-partition oracle
+    run, and the last band ends on H[m][n]."""
+    m, n, world = 900, 1100, 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_nw, args=(r, world, port, m, n, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=240) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    from masa_cudalign_amd.bands import band_limits
+    s0, s1 = pkg.seqgen.related_pair(m, n, cfg=44)
+    lim = band_limits(n, [1] * world)
+    kw = dict(recurrence=oracle.NEEDLEMAN_WUNSCH, first_row_type=oracle.INIT_WITH_GAPS,
+              first_col_type=oracle.INIT_WITH_GAPS, best_mode=oracle.BEST_LAST_CELL)
+    for rank in range(world):
+        ref = oracle.stage1(s0, s1[:lim[rank + 1]], want_last_col=True, **kw)
+        assert np.array_equal(res[rank], ref["last_col"][1:]), rank
+    full = oracle.stage1(s0, s1, **kw)
+    assert int(res[world - 1][-1, 0]) == full["best"][2]

@@ -53,3 +53,53 @@ def test_two_bands_two_processes_one_gpu(pkg, oracle):
     want = (ref["best"][0] - 1, ref["best"][1] - 1, ref["best"][2])
     for rank, best, gbest in res:
         assert gbest == want, (rank, best, gbest, want)
+
+
+def _worker_nw(rank, world, port, m, n, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    import __graft_entry__ as graft
+    pkg = graft.load_package()
+    from masa_cudalign_amd.bands import BandRunner, band_limits
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        s0, s1 = pkg.seqgen.related_pair(m, n, cfg=45)
+        lim = band_limits(n, [1] * world)
+        al = pkg.MI355Aligner(device=0, rows_per_lane=4, waves=64)
+        al.setSequences(s0, s1)
+        runner = BandRunner(al, dist=dist, rank=rank, world=world, device=None, segment_rows=512)
+        got = {}
+        runner.run(m, lim[rank], lim[rank + 1], recurrence=pkg.NEEDLEMAN_WUNSCH, track_best=False,
+                   first_row_init_type=pkg.INIT_WITH_GAPS, first_col_init_type=pkg.INIT_WITH_GAPS,
+                   want_last_row=True, before_end=lambda eng: got.update(row=eng.streamReadLastRow()))
+        al.close()
+        q.put((rank, got["row"]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_global_nw_three_bands_three_processes_one_gpu(pkg, oracle):
+    """C5's recurrence through the band driver with the real engine: global NW, gap-initialised borders, three
+    bands (the middle one receives and sends while its kernel runs); the bands' last-row slices put together are
+    the last row of the one-partition oracle run, ending on H[m][n]."""
+    import numpy as np
+    m, n, world = 5000, 6500, 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_nw, args=(r, world, port, m, n, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=500) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    s0, s1 = pkg.seqgen.related_pair(m, n, cfg=45)
+    ref = oracle.stage1(s0, s1, recurrence=oracle.NEEDLEMAN_WUNSCH, first_row_type=oracle.INIT_WITH_GAPS,
+                        first_col_type=oracle.INIT_WITH_GAPS, want_last_row=True, best_mode=oracle.BEST_LAST_CELL)
+    row = np.concatenate([res[r] for r in range(world)])
+    assert np.array_equal(row, ref["last_row"][1:])
+    assert int(row[-1, 0]) == ref["best"][2]
