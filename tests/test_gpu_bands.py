@@ -103,3 +103,68 @@ def test_global_nw_three_bands_three_processes_one_gpu(pkg, oracle):
     row = np.concatenate([res[r] for r in range(world)])
     assert np.array_equal(row, ref["last_row"][1:])
     assert int(row[-1, 0]) == ref["best"][2]
+
+
+def _worker_device_columns(q):
+    """fresh process: torch's HIP runtime first (as in bench.py), then the engine"""
+    import torch
+    torch.cuda.init()
+    import numpy as np
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import __graft_entry__ as graft
+    from helpers import load_golden, make_pair, digest
+    pkg = graft.load_package()
+    from masa_cudalign_amd.bands import band_limits, canonical_best
+    ch = load_golden()["chain"]
+    s0, s1 = make_pair(pkg, ch["seq"])
+    n, parts, m = len(s1), ch["parts"], len(s0)
+    lim = band_limits(n, [1] * parts)
+    al = pkg.MI355Aligner(device=0)
+    al.setSequences(s0, s1)
+    dcol, corner, cands, ok = None, None, [], True
+    for k in range(parts):
+        part = pkg.Partition(0, lim[k], m, lim[k + 1])
+        kw = dict(want_last_column=True)
+        if dcol is not None:
+            kw.update(first_column_init_type=pkg.INIT_WITH_CUSTOM_DATA, stream_first_column=True, first_column=corner)
+        al.streamBegin(part, **kw)
+        out = torch.empty((m, 2), dtype=torch.int32, device="cuda:0")
+        fed = read = 0
+        while True:
+            if dcol is not None and fed < m:
+                ln = min(1000, m - fed)
+                al.streamFeedColumnDevice(fed, dcol[fed:fed + ln].data_ptr(), ln)
+                fed += ln
+            rows, fin = al.streamPoll()
+            if rows > read:                      # drain what is complete while the kernel is still running
+                al.streamReadColumnDevice(read, out[read:rows].data_ptr(), rows - read)
+                read = rows
+            if fin:
+                break
+        if read < m:
+            al.streamReadColumnDevice(read, out[read:].data_ptr(), m - read)
+        best, _ = al.streamEnd()
+        newcol = np.concatenate([np.array([[0, -pkg.INF]], dtype=np.int32), out.cpu().numpy()])
+        if k < parts - 1:
+            ok = ok and digest(newcol) == ch["boundary_columns"]["STEP-%d.tmp" % (k + 1)]
+        dcol, corner = out, newcol[:1]
+        cands.append(best)
+        run = canonical_best(cands)
+        ok = ok and [run[0] + 1, run[1] + 1, run[2]] == ch["band_bests"][k]
+    al.close()
+    q.put(bool(ok))
+
+
+@pytest.mark.timeout(600)
+def test_chain_with_device_tensor_columns(pkg):
+    """the reference's --split chain with the boundary column travelling as a DEVICE tensor (what an RCCL send/recv
+    hands over: mi355sw_stream_read_column_device / mi355sw_stream_feed_column_device on the engine's copy stream
+    while the strip kernel runs): boundary columns and running bests match the fixture"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_worker_device_columns, args=(q,))
+    p.start()
+    assert q.get(timeout=500) is True
+    p.join(timeout=60)
+    assert p.exitcode == 0
