@@ -8,10 +8,12 @@
 One "step" = one complete Stage-1 pass (score + canonical position) over the synthetic pair with both
 sequences already resident in HBM.
   N = 1 : BASELINE config C2, 3,000,000 x 3,000,000 unrelated random ACGT, local SW, score-only.
-  N > 1 : weak scaling, per-GPU work fixed at 9e12 cells: (3,000,000*N) x 3,000,000, seq1 cut into N
-          column bands, boundary column streamed rank g -> g+1 while all strip kernels run (bands.py): through
-          pinned zero-copy host columns + gloo by default, RCCL send/recv of device tensors with
-          MI355SW_BENCH_COMM=nccl; barrier, best-score all_gather and timing all_reduce go over RCCL.
+  N > 1 : weak scaling, per-GPU work fixed at 3.6e13 cells: (12,000,000*N) x 3,000,000 (tall like BASELINE's C4/C5:
+          the start-up of a chain of column bands is N-1 band sweeps, whatever the height), seq1 cut into N column
+          bands; the boundary column goes GPU to GPU through column ports (bands.py transport "p2p": band g's strip
+          kernel stores its last column into band g+1's HBM over xGMI and publishes the row count, band g+1's kernel
+          polls it); barrier, best-score all_gather and timing all_reduce go over RCCL, the 80-byte port handles
+          over a gloo side group.  MI355SW_BENCH_COMM=host selects the pinned-host + gloo transport instead.
 Rank 0 prints ONE JSON line.  GCUPS convention of the reference: cells = m*n (sw_stage1.cpp:440-448).
 """
 import argparse
@@ -27,18 +29,34 @@ sys.path.insert(0, ROOT)
 import __graft_entry__ as graft  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0                 # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-# VALU issue measured on this chip (tools/micro_valu.hip): one wave64 instruction (int32 or packed 2x16)
-# per 4 cycles per SIMD, i.e. 0.59 wave-instructions/ns/SIMD at the 2.38 GHz the chip holds under this load
-VALU_PEAK_WAVE_INSTR = 256 * 4 * 0.59e9
-# HBM-side traffic of one launch from the PMC passes (profiles/r01_pk16_hbm_pmc.json: FETCH_SIZE x2 gfx950
-# correction + WRITE_SIZE), keyed by (kernel, m, n, strip_rows); other configurations report null
-PMC_TRAFFIC_BYTES = {("pk16", 3000000, 3000000, 1536): 112130775680.0}
-# VALU instructions per wave-step (SQ_INSTS_VALU / wave-steps; one step = strip_rows cells).  pk16/1536 is
-# measured (profiles/r01_pk16_sq_pmc.json: 128.5); the other packed heights scale its 9.65 per packed row
-# pair + 12 per step; int32 figures are from profiles/r01_int32_sq_pmc.json
-VALU_PER_STEP = {("int32", 256): 47.0, ("int32", 512): 86.3, ("int32", 1024): 165.0,
-                 ("pk16", 256): 31.3, ("pk16", 512): 50.6, ("pk16", 768): 69.9, ("pk16", 1024): 89.2,
-                 ("pk16", 1536): 128.5, ("pk16", 2048): 166.4}
+# VALU issue of the instruction class the packed kernel is made of (VOP3P, v_perm, DPP: "slow" class, 4 cycles per
+# wave64 instruction per SIMD whatever the occupancy), measured with controlled placement: v_pk_max_i16 at 4
+# wavefronts per SIMD = 0.536 wave-instructions/ns/SIMD (profiles/r02_valu_issue_rate.md, r02_micro_valu3_survey.txt)
+VALU_PEAK_WAVE_INSTR = 256 * 4 * 0.536e9
+# PMC-derived figures (HBM traffic per launch, VALU instructions per wave-step) are only quoted when they were
+# measured on THIS build of the kernels: profiles/pmc_index.json is keyed by kernel_build_id() (tools/pmc_collect.py
+# writes it from rocprofv3 --pmc passes); anything else is reported as null, never as a stale constant
+PMC_INDEX = os.path.join(ROOT, "profiles", "pmc_index.json")
+
+
+def kernel_build_id():
+    """sha256 over everything the device code is built from"""
+    import hashlib
+    h = hashlib.sha256()
+    src = os.path.join(graft.PKG_DIR, "csrc")
+    for fn in sorted(os.listdir(src)):
+        if fn.endswith((".hip", ".inc", ".h", ".py", ".sh")) or fn == "Makefile":
+            h.update(fn.encode())
+            h.update(open(os.path.join(src, fn), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def pmc_lookup(kernel, m, n, strip_rows):
+    try:
+        idx = json.load(open(PMC_INDEX))
+    except (OSError, ValueError):
+        return None
+    return idx.get(kernel_build_id(), {}).get("%s:%dx%d:%d" % (kernel, m, n, strip_rows))
 
 
 def cpu_baseline(pkg, seconds_budget=20.0):
@@ -99,7 +117,9 @@ def main():
     ap.add_argument("--size", type=int, default=3000000, help="n (and m per GPU) of the synthetic pair")
     ap.add_argument("--rows-per-lane", type=int, default=int(os.environ.get("MI355SW_R", "0")))
     ap.add_argument("--waves", type=int, default=int(os.environ.get("MI355SW_WAVES", "0")))
+    ap.add_argument("--tall", type=int, default=4, help="N > 1: rows per GPU = tall * size (weak scaling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-target-shape", action="store_true", help="N = 1: skip the 228 M-row north-star-height step")
     args = ap.parse_args()
 
     import torch
@@ -122,32 +142,28 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     coll_device = torch.device("cpu") if rehearse else device
-    # boundary-column transport between bands: "host" = pinned zero-copy columns + gloo between the
-    # rank processes (no GPU queue involved while the persistent kernels run; default), "nccl" = RCCL
-    # send/recv of device tensors over xGMI (needs free CU resources next to the strip kernel)
-    comm = os.environ.get("MI355SW_BENCH_COMM", "host")
+    # boundary-column transport between bands: "p2p" = column ports, GPU to GPU (default); "host" = pinned
+    # zero-copy columns + gloo between the rank processes
+    comm = os.environ.get("MI355SW_BENCH_COMM", "p2p")
+    if comm not in ("p2p", "host"):
+        raise SystemExit("MI355SW_BENCH_COMM must be p2p or host")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if rehearse:
             dist.init_process_group("gloo", rank=rank, world_size=world)
-            comm = "host"
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
-        p2p_group = dist.new_group(backend="gloo") if comm != "nccl" else None
+        p2p_group = dist.new_group(backend="gloo")     # host-side messages between neighbours (port handles / segments)
 
     pkg = graft.load_package()
     from masa_cudalign_amd.bands import BandRunner, band_limits
 
     n = args.size
-    m = args.size * world
+    m = args.size * (1 if world == 1 else args.tall * world)
     s0, s1 = pkg.seqgen.unrelated_pair(m, n, cfg=2)
     waves = args.waves
     if rehearse and waves == 0:
         waves = 1024 // world // 2        # all ranks' strip kernels must be resident on the one GPU together
-    if waves == 0 and world > 1 and comm == "nccl":
-        # every strip wavefront owns a whole SIMD; RCCL's send/recv kernels need SIMDs of
-        # their own, so leave 32 CUs' worth unclaimed (experimental transport -- "host" is the default)
-        waves = (256 - 32) * 4
     # N > 1: strip height from the chain model (bands.rows_per_lane_for_bands)
     lim = band_limits(n, [1] * world)
     rows_per_lane = args.rows_per_lane
@@ -158,7 +174,7 @@ def main():
     al.setSequences(s0, s1)            # H2D once, outside the timed region
     j0, j1 = lim[rank], lim[rank + 1]
 
-    class _Dist:                       # boundary-column transport: RCCL p2p (device tensors) or gloo (host)
+    class _Dist:                       # host-side neighbour messages (gloo side group) + collectives (RCCL)
         def __init__(self):
             self.group = p2p_group if world > 1 else None
 
@@ -173,9 +189,9 @@ def main():
 
     # block pruning is left off: C2 is an unrelated pair, on which the reference's (default-on) pruning
     # prunes nothing either, and the engine's kernel without the skip path is the faster one
-    runner = BandRunner(al, dist=_Dist() if world > 1 else None, rank=rank, world=world,
-                        device=(device if (world > 1 and comm == "nccl") else None), segment_rows=1 << 15)
-    if world > 1 and comm != "nccl":
+    runner = BandRunner(al, dist=_Dist() if world > 1 else None, rank=rank, world=world, device=None,
+                        segment_rows=1 << 15, transport=comm)
+    if world > 1:
         runner.reduce_best = lambda b, _r=runner: _reduce_cpu(dist, b, world, coll_device)
 
     def one_step():
@@ -213,6 +229,8 @@ def main():
         alg_bytes = st["algorithmic_bytes"]
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9
         band_cells = float(m) * float(j1 - j0)
+        kname = "pk16" if st["profile_kernel"] == 2 else "int32"
+        pmc = pmc_lookup(kname, m, j1 - j0, st["strip_rows"]) if world == 1 else None
         out = {
             "metric": "GCUPS (DP cells/sec) Stage-1", "value": gcups, "unit": "GCUPS",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -220,22 +238,25 @@ def main():
             "vs_baseline": None, "dtype": "i16x2 (packed, exact; int32 fallback)" if st["profile_kernel"] == 2 else "int32",
             "data": "synthetic",
             "config": {"workload": ("C2: %dx%d unrelated random ACGT, local SW, score-only" % (m, n)) if world == 1 else
-                       ("weak scaling of C2: (%d*%d)x%d, %d column bands of %d columns, boundary column streamed rank g -> g+1"
-                        % (args.size, world, n, world, n // world)),
+                       ("weak scaling, %d x C2's cells per GPU: (%d*%d)x%d unrelated random ACGT, local SW, score-only; "
+                        "%d column bands of %d columns, boundary column GPU to GPU (%s)"
+                        % (args.tall, args.size * args.tall, world, n, world, n // world, comm)),
                        "m": m, "n": n, "bands": world, "strip_rows": st["strip_rows"], "waves_per_gpu": st["waves"],
                        "kernel": {2: "pk16", 1: "int32-profile", 0: "int32-generic"}[st["profile_kernel"]],
-                       "comm": comm if world > 1 else "none"},
+                       "comm": comm if world > 1 else "none", "kernel_build_id": kernel_build_id()},
             "best": {"i": best[0] + 1, "j": best[1] + 1, "score": best[2]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": (PMC_TRAFFIC_BYTES.get(("pk16" if st["profile_kernel"] == 2 else "int32", m, n,
-                                                            st["strip_rows"])) if world == 1 else None),
-                         "traffic_unit": "bytes per launch (rocprofv3 PMC, profiles/r01_pk16_hbm_pmc.json)",
+                         "traffic": pmc["traffic_bytes"] if pmc else None,
+                         "traffic_source": (pmc["source"] + " (rocprofv3 --pmc passes on this kernel build, bytes per launch)") if pmc
+                                           else "not measured on this kernel build (profiles/pmc_index.json has no entry)",
                          "kernel": "sw_strip_kernel_pk16" if st["profile_kernel"] == 2 else "sw_strip_kernel",
                          "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_bytes,
                          "note": "scan kernel: 17 B per column per %d-row strip; the binding unit is VALU issue" % st["strip_rows"]},
-            "valu_roofline": _valu(st, band_cells, k_ms),
+            "valu_roofline": _valu(st, band_cells, k_ms, pmc),
         }
+        if world == 1 and not args.no_target_shape:
+            out["target_shape"] = target_shape(pkg, local_rank, check=not args.no_cpu_baseline)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pkg)
             out["cpu_baseline_all_cores"] = cpu_baseline_mt(pkg)
@@ -246,12 +267,45 @@ def main():
         dist.destroy_process_group()
 
 
-def _valu(st, band_cells, k_ms):
-    kind = "pk16" if st["profile_kernel"] == 2 else "int32"
-    per_step = VALU_PER_STEP.get((kind, st["strip_rows"]), 0.0832 * st["strip_rows"])
+def target_shape(pkg, device, check=True):
+    """One step at the north star's HEIGHT: 228,000,000 x 1,000,000 unrelated ACGT, local SW, one launch (111 329
+    strips of 2048 rows, two-phase best).  The full 228 M x 228 M matrix is 228 such bands (~2.3 h); this is the part of
+    it a bench run can afford.  The reported cell is checked by the oracle on the 600 x 600 window that ends at it."""
+    from masa_cudalign_amd.bands import BandRunner
+    m, n = 228000000, 1000000
+    s0, s1 = pkg.seqgen.unrelated_pair(m, n, cfg=5)
+    al = pkg.MI355Aligner(device=device)
+    try:
+        al.setSequences(s0, s1)
+        t0 = time.time()
+        best = BandRunner(al).run(m, 0, n)
+        dt = time.time() - t0
+        st = al.getStatistics()
+    finally:
+        al.close()
+    out = {"workload": "north-star height: %dx%d unrelated random ACGT, local SW, score + canonical position, one launch" % (m, n),
+           "value": float(m) * n / dt / 1e9, "unit": "GCUPS", "seconds": dt, "kernel_ms": st["kernel_ms"],
+           "strip_rows": st["strip_rows"], "strips": st["strips"], "kernel_launches": st["kernel_launches"],
+           "best": {"i": best[0] + 1, "j": best[1] + 1, "score": best[2]}}
+    if check:
+        oracle = graft.load_oracle()
+        i, j = best[0] + 1, best[1] + 1
+        i0, j0 = max(0, i - 600), max(0, j - 600)
+        ref = oracle.stage1(s0[i0:i], s1[j0:j], want_last_row=True)
+        out["check"] = {"oracle_window": "600x600 ending at the reported cell",
+                        "ok": bool(ref["best"][2] == best[2] and int(ref["last_row"][-1][0]) == best[2])}
+    return out
+
+
+def _valu(st, band_cells, k_ms, pmc):
+    if not pmc or not pmc.get("valu_per_step"):
+        return {"valu_instr_per_step": None, "frac": None, "peak_wave_instr_per_s": VALU_PEAK_WAVE_INSTR,
+                "note": "SQ_INSTS_VALU not measured on this kernel build (profiles/pmc_index.json has no entry)"}
+    per_step = pmc["valu_per_step"]
     achieved = band_cells / st["strip_rows"] * per_step / (k_ms * 1e-3)
     return {"valu_instr_per_step": per_step, "cells_per_step": st["strip_rows"], "achieved_wave_instr_per_s": achieved,
-            "peak_wave_instr_per_s": VALU_PEAK_WAVE_INSTR, "frac": achieved / VALU_PEAK_WAVE_INSTR}
+            "peak_wave_instr_per_s": VALU_PEAK_WAVE_INSTR, "frac": achieved / VALU_PEAK_WAVE_INSTR,
+            "source": pmc["source"], "peak_source": "profiles/r02_valu_issue_rate.md (v_pk_max_i16, 4 wavefronts per SIMD)"}
 
 
 def _reduce_cpu(dist, best, world, device):

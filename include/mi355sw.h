@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define MI355SW_ABI_VERSION 2
+#define MI355SW_ABI_VERSION 3
 
 /* M/libmasa/libmasaTypes.hpp:35-41  cell_t {int h; union{int f; int e;};} 8-byte aligned */
 typedef struct { int32_t h; int32_t f; } mi355sw_cell;
@@ -49,7 +49,9 @@ typedef struct { int32_t i0, j0, i1, j1; } mi355sw_partition;
 #define MI355SW_ENOMEM (-4)
 #define MI355SW_ETIMEOUT (-5)   /* a bounded in-kernel spin gave up             */
 #define MI355SW_ESTATE (-6)
-#define MI355SW_EOVERFLOW16 (-7) /* packed 16-bit kernel left its exact range: rerun with force_int32 */
+#define MI355SW_EOVERFLOW16 (-7) /* packed 16-bit kernel left its exact range: rerun with force_int32
+                                    (mi355sw_align_partition and mi355sw_process_block do that by themselves;
+                                    the streaming form reports it from poll/end, rows handed out before are exact) */
 
 typedef struct mi355sw_handle mi355sw_handle;
 
@@ -60,7 +62,7 @@ typedef struct {
                                 0 = choose from the partition size                                 */
     int32_t waves;           /* persistent wavefronts (reference: --blocks); 0 = one per SIMD      */
     int32_t flags;           /* MI355SW_F_*                                                          */
-    int64_t max_special_bytes; /* HBM budget for device-resident special rows, 0 = default (8 GiB) */
+    int64_t max_special_bytes; /* HBM budget for device-resident special rows, 0 = 60 % of the HBM free at stream_begin */
 } mi355sw_config;
 #define MI355SW_F_FORCE_GENERIC_COMPARE 1   /* raw byte compare kernels even if a profile fits */
 #define MI355SW_F_FORCE_INT32 2             /* never use the packed 16-bit SW kernel */
@@ -177,6 +179,15 @@ typedef struct {
                                            running best (AbstractBlockPruning::isBlockPrunable, SW only) */
     int32_t prune_rows, prune_cols;     /* rows/columns left from the partition origin to the end of the
                                            SUPER-partition (max_i - i0, max_j - j0); 0 = the partition's own */
+    int32_t first_column_port;          /* 1: the first column arrives in this handle's inbound column port, written by
+                                           the previous band's GPU (first_column_init_type must be CUSTOM_DATA;
+                                           first_column[0] = corner cell) */
+    int32_t last_column_port;           /* 1: the last column is stored straight into the next band's column port
+                                           (opened with mi355sw_port_open/attach) instead of being kept for
+                                           mi355sw_stream_read_column(); excludes want_last_column */
+    int32_t first_column_resume_rows;   /* restart of the SAME partition on this handle (int32 rerun after
+                                           MI355SW_EOVERFLOW16): rows of the streamed first column that were fed
+                                           before the restart are still in place and count as fed again */
 } mi355sw_stream_params;
 
 int mi355sw_stream_begin(mi355sw_handle* h, const mi355sw_partition* partition, const mi355sw_stream_params* p);
@@ -194,17 +205,39 @@ int mi355sw_stream_abort(mi355sw_handle* h);
 int mi355sw_stream_end(mi355sw_handle* h, mi355sw_score* best, int32_t* n_special_rows);
 /* per-strip best scores of the finished stream (for dispatch_score); returns count written */
 int mi355sw_stream_strip_scores(mi355sw_handle* h, mi355sw_score* out, int32_t max_count);
-/* raw device pointers of the engine's column buffers, for peer-to-peer (xGMI) transfers by the
- * caller (RCCL send/recv on these addresses); NULL if not allocated */
-void* mi355sw_stream_device_first_column(mi355sw_handle* h);
-void* mi355sw_stream_device_last_column(mi355sw_handle* h);
-/* device-pointer variants of feed/read (D2D on the engine's copy stream): `dev_cells` is a device
- * address on the engine's GPU, e.g. the landing buffer of an RCCL recv / the source of an RCCL send */
-int mi355sw_stream_feed_column_device(mi355sw_handle* h, int32_t row, const void* dev_cells, int32_t len);
-int mi355sw_stream_read_column_device(mi355sw_handle* h, int32_t row, void* dev_cells, int32_t len);
-/* tell the engine that rows [0,rows) of the device first-column buffer are now valid (after a
- * device-side transfer the caller performed itself) */
-int mi355sw_stream_publish_first_column(mi355sw_handle* h, int32_t rows);
+/* ---- column ports: the boundary column of a band chain, GPU to GPU over xGMI -------------------------------
+ * Replaces the reference's socket chain between forked processes (M/libmasa/libmasa.cpp:540-642,
+ * M/common/io/SocketCellsWriter.cpp, BufferedCellsWriter.cpp:57-66).  Band g+1 owns an inbound PORT in the HBM
+ * of its own GPU: (H,E) cells of its first column plus a row counter (fine-grained memory).  Band g maps that
+ * port (hipIpc between the rank processes, direct peer access inside one process); its strip kernel stores the
+ * last-column cells of every finished strip into it and then publishes the row count with a system-scope
+ * release store; band g+1's kernel polls the counter in its own HBM.  No host, no copy queue and no PCIe in the
+ * loop.  A port is used for ONE run of the chain (create it before the handle is handed to the neighbour). */
+typedef struct {
+    unsigned char ipc[64];   /* hipIpcMemHandle_t */
+    int64_t bytes;
+    int32_t rows;            /* capacity in DP rows (cells 1..rows; cell 0 = corner, written by the owner) */
+    int32_t device;          /* HIP ordinal of the owning GPU */
+} mi355sw_port_handle;
+/* owner side (band g+1): allocate the inbound port for `rows` rows, counter = 0; `out` may be sent to another process */
+int mi355sw_port_create(mi355sw_handle* h, int32_t rows, mi355sw_port_handle* out);
+/* writer side (band g), other process: map the neighbour's port as this handle's outbound port */
+int mi355sw_port_open(mi355sw_handle* h, const mi355sw_port_handle* remote);
+/* writer side, same process: `downstream`'s inbound port becomes `h`'s outbound port (peer access is enabled
+ * when the two handles sit on different GPUs) */
+int mi355sw_port_attach(mi355sw_handle* h, mi355sw_handle* downstream);
+/* owner side: counter back to 0 for another run of the chain; the caller makes sure that no writer is active
+ * (bands.py: the owner resets, THEN tells the writer to start) */
+int mi355sw_port_reset(mi355sw_handle* h);
+/* rows published so far in the inbound port (reads the counter from HBM; diagnostics, tests) */
+int mi355sw_port_rows_ready(mi355sw_handle* h, int32_t* rows);
+/* copies cells [row, row+len) of the inbound port's column to the host (diagnostics, tests) */
+int mi355sw_port_read(mi355sw_handle* h, int32_t row, mi355sw_cell* cells, int32_t len);
+/* device addresses of the inbound port for callers that move the column themselves (RCCL recv, hipMemcpyPeer):
+ * cells[1 + row] and the int32 row counter, which they must store with system scope AFTER the cells */
+int mi355sw_port_local_pointers(mi355sw_handle* h, void** cells, void** counter);
+/* release the inbound port and unmap the outbound one */
+int mi355sw_port_close(mi355sw_handle* h);
 
 /* device enumeration: X/cuda_util.cpp:191-287 (--list-gpus, GPU weights) */
 int mi355sw_device_count(void);

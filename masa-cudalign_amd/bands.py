@@ -5,9 +5,12 @@
 Replaces the reference's --fork/--split chain (M/libmasa/libmasa.cpp:497-642): forked processes
 joined by TCP sockets carrying cell_t (M/common/io/SocketCells{Reader,Writer}.cpp), best score
 relayed through AlignerPool signal files (M/stage1/sw_stage1.cpp:421-464).  Here the boundary
-column goes point-to-point through torch.distributed (backend nccl == RCCL over xGMI on the GPU
-box, gloo in the CPU tests) in row segments while the strip kernel keeps running, and the best
-score is an all_gather of one (score,i,j) triple reduced with BestScoreList's order.
+column goes GPU to GPU: band g+1 owns a column PORT in its own HBM, band g's strip kernel stores its
+last column straight into it over xGMI (peer-mapped through hipIpc) and publishes the row count with a
+system-scope release store that band g+1's kernel polls -- no host, copy queue or PCIe in the loop
+(transport "p2p").  The CPU tests' stand-in engine uses the "host" transport instead (row segments sent
+with torch.distributed send/recv, gloo).  The best score is an all_gather of one (score,i,j) triple
+reduced with BestScoreList's order.
 
 The compute engine is injected (`engine_factory`) so that the N>1 plumbing can be exercised on CPU
 with a stand-in; the product engine is MI355Aligner (HIP, no CPU fallback).
@@ -62,30 +65,72 @@ def canonical_best(cands):
 
 
 class BandRunner:
-    """Runs one band of the chain on this rank.  `dist` is torch.distributed (already initialised)
-    or None for a single band.  All ranks must call run() with the same m, n, weights, segment."""
+    """Runs one band of the chain on this rank.  `dist` is torch.distributed (already initialised) or an object
+    with send/recv/all_gather, or None for a single band.  All ranks must call run() with the same m.
 
-    def __init__(self, engine, dist=None, rank=0, world=1, device=None, segment_rows=1 << 16, prune_blocks=False):
+    transport = "p2p"  : the boundary column goes GPU to GPU (column ports, include/mi355sw.h): band g+1 owns a
+                         port in its own HBM, band g's strip kernel stores its last column straight into it over
+                         xGMI and publishes the row count with a system-scope release store; the hosts only
+                         exchange the 80-byte port handle before the kernels start.  Default on GPUs.
+                "host" : pinned zero-copy columns + send/recv of row segments between the rank processes (the
+                         reference's socket chain, libmasa.cpp:540-642); used by the CPU tests' stand-in engine
+                         and as a fallback.
+    `device` is only the device of the tensors used for collectives (reduce_best)."""
+
+    def __init__(self, engine, dist=None, rank=0, world=1, device=None, segment_rows=1 << 16, prune_blocks=False,
+                 transport="host"):
         self.engine, self.dist, self.rank, self.world = engine, dist, rank, world
         self.prune_blocks = prune_blocks
         self.device = device
         self.segment_rows = segment_rows
+        self.transport = transport if world > 1 else "none"
+        self._in_port = None         # PortHandle of this band's inbound port, and the rows it was made for
+        self._in_rows = 0
+        self._out_token = None       # handle bytes of the neighbour's port currently mapped
+        self.restarts = 0            # packed-kernel overflow restarts (int32 rerun) of the last run
 
     def _tensor(self, rows):
         import torch
-        return torch.empty((rows, 2), dtype=torch.int32, device=self.device if self.device is not None else "cpu")
+        return torch.empty((rows, 2), dtype=torch.int32, device="cpu")
 
-    def run(self, m, j0, j1, recurrence=SMITH_WATERMAN, track_best=True, first_row_init_type=INIT_WITH_ZEROES,
-            first_col_init_type=INIT_WITH_ZEROES, poll_sleep=0.0005, want_last_row=False, before_end=None):
-        """seq1 of the engine must already hold the whole horizontal sequence (or at least [j0,j1))."""
+    # -- p2p: port hand-shake, once per run ------------------------------------------------------------
+    def _exchange_ports(self, m):
+        """band g (> 0) makes its inbound port ready (created, or its counter reset) and THEN tells band g-1, which
+        only then starts its kernel: nothing can be published into a port before its owner has reset it."""
+        import torch
+        from .engine import PortHandle
         eng, dist = self.engine, self.dist
         first, last = self.rank == 0, self.rank == self.world - 1
+        if not first:
+            if self._in_port is None or self._in_rows != m:
+                self._in_port, self._in_rows = eng.portCreate(m), m
+            else:
+                eng.portReset()
+            tok = torch.frombuffer(bytearray(self._in_port.tobytes()), dtype=torch.uint8).clone()
+            dist.send(tok, dst=self.rank - 1)
+        if not last:
+            tok = torch.empty(len(PortHandle().tobytes()), dtype=torch.uint8)
+            dist.recv(tok, src=self.rank + 1)
+            b = bytes(tok.numpy().tobytes())
+            if b != self._out_token:
+                eng.portOpen(PortHandle.frombytes(b))
+                self._out_token = b
+
+    def run(self, m, j0, j1, recurrence=SMITH_WATERMAN, track_best=True, first_row_init_type=INIT_WITH_ZEROES,
+            first_col_init_type=INIT_WITH_ZEROES, poll_sleep=0.0005, want_last_row=False, before_end=None,
+            force_int32=False):
+        """seq1 of the engine must already hold the whole horizontal sequence (or at least [j0,j1))."""
+        from .engine import AlignerError
+        eng, dist = self.engine, self.dist
+        first, last = self.rank == 0, self.rank == self.world - 1
+        p2p = self.transport == "p2p"
         part = Partition(0, j0, m, j1)
         seg = self.segment_rows
         nseg = (m + seg - 1) // seg
         kw = dict(recurrence_type=recurrence, track_best=track_best,
                   first_row_init_type=first_row_init_type, first_row_start_offset=j0,
-                  want_last_column=not last, want_last_row=want_last_row,
+                  want_last_column=(not last) and not p2p, last_column_port=(not last) and p2p,
+                  want_last_row=want_last_row, force_int32=force_int32,
                   # block pruning: never when the matrix is split over processes (as the reference,
                   # libmasa.cpp:1318-1321); for a single band it is the caller's choice (self.prune_blocks)
                   prune_blocks=(self.prune_blocks and self.world == 1 and recurrence == SMITH_WATERMAN and track_best))
@@ -98,12 +143,16 @@ class BandRunner:
             if first_row_init_type != INIT_WITH_ZEROES:
                 open_ = 3 if first_row_init_type == 1 else 0
                 corner[0, 0] = -2 * j0 - open_ if j0 > 0 else 0
-            kw.update(first_column_init_type=INIT_WITH_CUSTOM_DATA, stream_first_column=True, first_column=corner)
+            kw.update(first_column_init_type=INIT_WITH_CUSTOM_DATA, first_column=corner,
+                      stream_first_column=not p2p, first_column_port=p2p)
+        if p2p:
+            self._exchange_ports(m)
         eng.streamBegin(part, **kw)
+        self.restarts = 0
 
-        use_dev = self.device is not None and str(self.device).startswith("cuda")
         lock = threading.Lock()          # the engine handle is driven by one thread at a time
         errors = []
+        fed = [0]                        # rows of the inbound column handed to the engine so far (host transport)
 
         def receiver():
             # inbound boundary column: blocking recv of row segments from the left neighbour
@@ -114,15 +163,32 @@ class BandRunner:
                     buf = self._tensor(ln)
                     dist.recv(buf, src=self.rank - 1)
                     with lock:
-                        if use_dev:
-                            eng.streamFeedColumnDevice(r0, buf.data_ptr(), ln)
-                        else:
-                            eng.streamFeedColumn(r0, buf.numpy())
+                        eng.streamFeedColumn(r0, buf.numpy())
+                        fed[0] = r0 + ln
             except BaseException as e:     # surfaced by the main loop
                 errors.append(e)
 
+        def restart_int32():
+            """the packed kernel left its exact range: everything handed out so far is exact (the engine only
+            reports rows below the failing strip), so the band starts again on the int32 kernel and REPLAYS --
+            the inbound rows already received are still in the engine's column (pinned, or the port), outbound
+            segments already sent are not sent again (a port is simply written again with the same cells)."""
+            try:
+                eng.streamAbort()
+            except AlignerError:
+                pass
+            try:
+                eng.streamEnd()
+            except AlignerError:
+                pass
+            kw2 = dict(kw, force_int32=True)
+            if not first and not p2p:
+                kw2["first_column_resume_rows"] = fed[0]
+            eng.streamBegin(part, **kw2)
+            self.restarts += 1
+
         rx = None
-        if not first:
+        if not first and not p2p:
             rx = threading.Thread(target=receiver, daemon=True)
             rx.start()
         send_q = 0
@@ -133,46 +199,51 @@ class BandRunner:
         stall_abort = float(os.environ.get("MI355SW_BAND_STALL_S", "900"))
         t_dbg = t_prog = time.time()
         seen = (-1, -1)
+        rows_done, fin = 0, False
         while True:
             now = time.time()
             if now - t_dbg >= (1.0 if debug else 10.0):
                 t_dbg = now
-                with lock:
-                    rd, fn = eng.streamPoll()
-                if (rd, send_q) != seen:
-                    seen, t_prog = (rd, send_q), now
+                if (rows_done, send_q) != seen:
+                    seen, t_prog = (rows_done, send_q), now
                 if debug or now - t_prog >= 10.0:
                     sys.stderr.write("[band %d/%d] rows_done=%d/%d finished=%d segments_sent=%d/%d no progress for %.0f s\n"
-                                     % (self.rank, self.world, rd, m, int(fn), send_q, nseg, now - t_prog))
+                                     % (self.rank, self.world, rows_done, m, int(fin), send_q, nseg, now - t_prog))
                     sys.stderr.flush()
                 if now - t_prog >= stall_abort:
                     errors.append(RuntimeError("band %d/%d: no progress for %.0f s (rows_done=%d/%d, segments_sent=%d/%d)"
-                                               % (self.rank, self.world, now - t_prog, rd, m, send_q, nseg)))
+                                               % (self.rank, self.world, now - t_prog, rows_done, m, send_q, nseg)))
             if errors:
                 with lock:
                     eng.streamAbort()
-                    eng.streamEnd()
+                    try:
+                        eng.streamEnd()
+                    except AlignerError:
+                        pass
                 raise errors[0]
             with lock:
-                rows_done, fin = eng.streamPoll()
+                try:
+                    rows_done, fin = eng.streamPoll()
+                except AlignerError as e:
+                    if "EOVERFLOW16" not in str(e) or kw.get("force_int32") or self.restarts > 0:
+                        raise
+                    restart_int32()
+                    continue
             progressed = False
-            # outbound boundary column: every complete segment goes to the right neighbour
-            while not last and send_q < nseg:
+            # outbound boundary column (host transport): every complete segment goes to the right neighbour
+            while not last and not p2p and send_q < nseg:
                 r0 = send_q * seg
                 ln = min(seg, m - r0)
                 if rows_done < r0 + ln:
                     break
                 buf = self._tensor(ln)
                 with lock:
-                    if use_dev:
-                        eng.streamReadColumnDevice(r0, buf.data_ptr(), ln)
-                    else:
-                        import torch
-                        buf.copy_(torch.from_numpy(eng.streamReadColumn(r0, ln)))
+                    import torch
+                    buf.copy_(torch.from_numpy(eng.streamReadColumn(r0, ln)))
                 dist.send(buf, dst=self.rank + 1)
                 send_q += 1
                 progressed = True
-            if fin and (last or send_q >= nseg):
+            if fin and (last or p2p or send_q >= nseg):
                 break
             if not progressed:
                 time.sleep(poll_sleep)
@@ -180,7 +251,25 @@ class BandRunner:
             rx.join()
         if before_end is not None:       # e.g. read this band's slice of the last row while the stream is open
             before_end(eng)
-        best, _ = eng.streamEnd()
+        try:
+            best, _ = eng.streamEnd()
+        except AlignerError as e:        # e.g. reported by the exact-position pass of a very tall band
+            if "EOVERFLOW16" not in str(e) or kw.get("force_int32") or self.restarts > 0:
+                raise
+            with lock:
+                kw2 = dict(kw, force_int32=True)
+                if not first and not p2p:
+                    kw2["first_column_resume_rows"] = fed[0]
+                eng.streamBegin(part, **kw2)
+                self.restarts += 1
+            while True:
+                rows_done, fin = eng.streamPoll()
+                if fin:
+                    break
+                time.sleep(poll_sleep)
+            if before_end is not None:
+                before_end(eng)
+            best, _ = eng.streamEnd()
         return best
 
     def reduce_best(self, best):

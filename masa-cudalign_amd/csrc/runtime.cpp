@@ -69,6 +69,14 @@ struct mi355sw_handle {
     PinBuf p_first_col, p_last_col;  // streamed first column / last column (zero-copy)
     bool first_col_pinned = false;
     int* h_pinned = nullptr;        // [0] strips_done (kernel->host) [16] first_col_ready (host->kernel) [32] abort (host->kernel)
+                                    // [48] error mirror (kernel->host, written before [0] moves past the failing strip)
+    // column ports (xGMI boundary column): inbound = fine-grained HBM of this GPU, outbound = the next band's inbound
+    // port mapped here (hipIpc / peer access).  Layout: 256 control bytes (int32 row counter at +0), then m+1 cells.
+    void* in_port = nullptr; size_t in_port_bytes = 0; int in_port_rows = 0;
+    void* out_port = nullptr; int out_port_rows = 0; bool out_port_ipc = false;
+    bool first_col_port = false;    // active stream reads its first column from in_port
+    int clean_rows = 0;             // rows reported by the last poll that saw no kernel error
+    bool overflow_seen = false;
     std::vector<int4> strip_best_host;
 
     // stream state
@@ -201,6 +209,7 @@ void mi355sw_destroy(mi355sw_handle* h) {
     if (!h) return;
     (void) hipSetDevice(h->device);
     if (h->active) { mi355sw_stream_abort(h); mi355sw_stream_end(h, nullptr, nullptr); }
+    mi355sw_port_close(h);
     release(h->d_seq0); release(h->d_seq1); release(h->d_bus); release(h->d_first_col);
     if (h->p_first_col.p) (void) hipHostFree(h->p_first_col.p);
     if (h->p_last_col.p) (void) hipHostFree(h->p_last_col.p);
@@ -400,9 +409,19 @@ int mi355sw_stream_begin(mi355sw_handle* h, const mi355sw_partition* part, const
     if ((rc = ensure(h, h->d_kargs, sizeof(KernelArgs)))) return rc;
     if (h->two_phase && (rc = ensure(h, h->d_ckpt, sizeof(int2) * (size_t) h->ckpt_pitch * h->n_ckpt))) return rc;
     const bool need_first_col = (p->first_column_init_type != MI355SW_INIT_WITH_ZEROES);
-    h->first_col_pinned = need_first_col && p->first_column_init_type == MI355SW_INIT_WITH_CUSTOM_DATA &&
+    h->first_col_port = false;
+    if (p->first_column_port) {
+        if (p->first_column_init_type != MI355SW_INIT_WITH_CUSTOM_DATA) FAIL(h, MI355SW_EINVAL, "first_column_port needs INIT_WITH_CUSTOM_DATA");
+        if (!h->in_port || h->in_port_rows < m) FAIL(h, MI355SW_ESTATE, "first_column_port without an inbound port of >= %d rows (mi355sw_port_create)", m);
+        h->first_col_port = true;
+    }
+    if (p->last_column_port) {
+        if (p->want_last_column) FAIL(h, MI355SW_EINVAL, "last_column_port excludes want_last_column");
+        if (!h->out_port || h->out_port_rows < m) FAIL(h, MI355SW_ESTATE, "last_column_port without an outbound port of >= %d rows (mi355sw_port_open/attach)", m);
+    }
+    h->first_col_pinned = need_first_col && !h->first_col_port && p->first_column_init_type == MI355SW_INIT_WITH_CUSTOM_DATA &&
                           p->stream_first_column;
-    if (need_first_col && !h->first_col_pinned && (rc = ensure(h, h->d_first_col, sizeof(int2) * ((size_t) m + 1)))) return rc;
+    if (need_first_col && !h->first_col_pinned && !h->first_col_port && (rc = ensure(h, h->d_first_col, sizeof(int2) * ((size_t) m + 1)))) return rc;
     if (h->first_col_pinned && (rc = ensure_pinned(h, h->p_first_col, sizeof(int2) * ((size_t) m + 1)))) return rc;
     if (p->want_last_column && (rc = ensure_pinned(h, h->p_last_col, sizeof(int2) * ((size_t) m + 1)))) return rc;
     if (p->want_last_row && (rc = ensure(h, h->d_last_row, sizeof(int2) * ((size_t) n + 64)))) return rc;
@@ -435,7 +454,14 @@ int mi355sw_stream_begin(mi355sw_handle* h, const mi355sw_partition* part, const
     // first column
     h->h_pinned[16] = 0;
     if (need_first_col) {
-        if (p->first_column_init_type == MI355SW_INIT_WITH_CUSTOM_DATA) {
+        if (h->first_col_port) {
+            // the rows come from the previous band's GPU; only the corner cell is this side's to write.  The
+            // counter is NOT touched: the neighbour may have started publishing before this call.
+            mi355sw_cell corner = {0, -MI355SW_INF};
+            if (p->first_column) corner = p->first_column[0];
+            HIPCHK(h, hipMemcpyAsync((char*) h->in_port + 256, &corner, sizeof(corner), hipMemcpyHostToDevice, h->stream));
+            HIPCHK(h, hipStreamSynchronize(h->stream));
+        } else if (p->first_column_init_type == MI355SW_INIT_WITH_CUSTOM_DATA) {
             if (!p->stream_first_column) {
                 if (!p->first_column) FAIL(h, MI355SW_EINVAL, "custom first column without data");
                 HIPCHK(h, hipMemcpyAsync(h->d_first_col.p, p->first_column, sizeof(int2) * ((size_t) m + 1),
@@ -448,6 +474,11 @@ int mi355sw_stream_begin(mi355sw_handle* h, const mi355sw_partition* part, const
                 mi355sw_cell corner = {0, -MI355SW_INF};
                 if (p->first_column) corner = p->first_column[0];
                 memcpy(h->p_first_col.p, &corner, sizeof(corner));
+                if (p->first_column_resume_rows > 0) {
+                    if (p->first_column_resume_rows > m) FAIL(h, MI355SW_EINVAL, "first_column_resume_rows > rows");
+                    h->fed_rows = p->first_column_resume_rows;
+                    h->h_pinned[16] = p->first_column_resume_rows;
+                }
             }
         } else {
             // InitialCellsReader (InitialCellsReader.cpp:84-108) generated on the host once
@@ -485,8 +516,9 @@ int mi355sw_stream_begin(mi355sw_handle* h, const mi355sw_partition* part, const
     a.strip_row0 = 0;
     a.strip_index0 = 0;
     a.bus = (int2*) h->d_bus.p;
-    a.first_col = need_first_col ? (const int2*) (h->first_col_pinned ? h->p_first_col.p : h->d_first_col.p) : nullptr;
-    a.last_col = p->want_last_column ? (int2*) h->p_last_col.p : nullptr;
+    a.first_col = need_first_col ? (const int2*) (h->first_col_port ? (void*) ((char*) h->in_port + 256) : (h->first_col_pinned ? h->p_first_col.p : h->d_first_col.p)) : nullptr;
+    a.last_col = p->want_last_column ? (int2*) h->p_last_col.p : (p->last_column_port ? (int2*) ((char*) h->out_port + 256) : nullptr);
+    a.peer_ready = p->last_column_port ? (int*) h->out_port : nullptr;
     a.special_rows = h->n_special > 0 ? (int2*) h->d_special.p : nullptr;
     a.special_pitch = h->special_pitch;
     a.special_interval_strips = h->n_special > 0 ? h->special_interval_strips : 0;
@@ -501,7 +533,19 @@ int mi355sw_stream_begin(mi355sw_handle* h, const mi355sw_partition* part, const
     a.error_flag = ctrl + 32;
     a.strips_done_dev = ctrl + 48;
     a.strips_done_host = getenv("MI355SW_NOHOST") ? nullptr : h->h_pinned + 0;
-    a.first_col_ready = (need_first_col && p->stream_first_column) ? h->h_pinned + 16 : nullptr;
+    a.first_col_ready = h->first_col_port ? (const int*) h->in_port : ((need_first_col && p->stream_first_column) ? h->h_pinned + 16 : nullptr);
+    __atomic_store_n(&h->h_pinned[48], 0, __ATOMIC_RELEASE);
+    a.host_error = h->h_pinned + 48;
+    a.fault_strip = -1;
+    if (const char* e = getenv("MI355SW_FAULT_OVERFLOW_STRIP")) a.fault_strip = atoi(e);   // test knob, packed kernel only
+    h->clean_rows = 0;
+    h->overflow_seen = false;
+    {
+        // waits on data another GPU or the host delivers: wall-time budget (10 ns ticks), MI355SW_WAIT_S seconds
+        double wait_s = 3600.0;
+        if (const char* e = getenv("MI355SW_WAIT_S")) { const double v = atof(e); if (v > 0) wait_s = v; }
+        a.wait_ticks = (long long) (wait_s * 1e8);
+    }
     __atomic_store_n(&h->h_pinned[32], 0, __ATOMIC_RELEASE);
     h->abort_strips = -1;
     a.host_abort = h->h_pinned + 32;
@@ -545,7 +589,9 @@ int mi355sw_stream_begin(mi355sw_handle* h, const mi355sw_partition* part, const
         h->strips >= 64 && n >= 16384 && !getenv("MI355SW_NOSEED")) {
         const int SEED_COLS = 2048;
         const int ws = std::min(h->strips, waves);
-        const size_t o_ctrl = 256, o_prog = 512, o_sb = o_prog + (((size_t) ws + 1) * 8 + 255) / 256 * 256;
+        // layout of the seed pass's scratch: [argument block | control words | progress | strip records | bus]
+        static_assert(sizeof(KernelArgs) <= 512, "the seed pass keeps its argument block in the first 512 bytes");
+        const size_t o_ctrl = 512, o_prog = 768, o_sb = o_prog + (((size_t) ws + 1) * 8 + 255) / 256 * 256;
         const size_t o_bus = o_sb + (size_t) ws * sizeof(int4);
         if ((rc = ensure(h, h->d_seed, o_bus + sizeof(int2) * (SEED_COLS + 64)))) return rc;
         char* base = (char*) h->d_seed.p;
@@ -560,6 +606,7 @@ int mi355sw_stream_begin(mi355sw_handle* h, const mi355sw_partition* part, const
         b.progress = (int*) (base + o_prog);
         b.ticket = ctrl2 + 0; b.abort_flag = ctrl2 + 16; b.error_flag = ctrl2 + 32; b.strips_done_dev = ctrl2 + 48;
         b.strips_done_host = nullptr; b.first_col_ready = nullptr; b.host_abort = nullptr;
+        b.peer_ready = nullptr; b.host_error = nullptr; b.fault_strip = -1;
         b.strip_best = (int4*) (base + o_sb);
         b.dbg = nullptr; b.trace = nullptr;
         b.independent = 1;                             // nobody waits for anybody: progress[0..ws] stays "all columns ready"
@@ -596,39 +643,126 @@ int mi355sw_stream_feed_column(mi355sw_handle* h, int32_t row, const mi355sw_cel
     return MI355SW_OK;
 }
 
-int mi355sw_stream_feed_column_device(mi355sw_handle* h, int32_t row, const void* dev_cells, int32_t len) {
-    if (!h || !h->active) return MI355SW_ESTATE;
-    if (row != h->fed_rows || len < 0 || row + len > h->m) FAIL(h, MI355SW_EINVAL, "feed_column_device out of order");
-    if (len == 0) return MI355SW_OK;
-    if (!h->first_col_pinned) FAIL(h, MI355SW_ESTATE, "feed_column_device without a streamed first column");
-    // D2H into the pinned column on the copy stream (a queue of its own: see mi355sw_create)
-    HIPCHK(h, hipMemcpyAsync((int2*) h->p_first_col.p + 1 + row, dev_cells, sizeof(int2) * (size_t) len,
-                             hipMemcpyDeviceToHost, h->copy));
-    HIPCHK(h, hipStreamSynchronize(h->copy));
-    h->fed_rows += len;
-    __atomic_store_n(&h->h_pinned[16], h->fed_rows, __ATOMIC_RELEASE);
-    return MI355SW_OK;
-}
-
-int mi355sw_stream_read_column_device(mi355sw_handle* h, int32_t row, void* dev_cells, int32_t len) {
-    if (!h || !h->active || !h->sp.want_last_column) return MI355SW_ESTATE;
-    if (row < 0 || len < 0 || row + len > h->m) FAIL(h, MI355SW_EINVAL, "read_column_device range");
-    HIPCHK(h, hipMemcpyAsync(dev_cells, (int2*) h->p_last_col.p + 1 + row, sizeof(int2) * (size_t) len,
-                             hipMemcpyHostToDevice, h->copy));
-    HIPCHK(h, hipStreamSynchronize(h->copy));
-    return MI355SW_OK;
-}
-
-int mi355sw_stream_publish_first_column(mi355sw_handle* h, int32_t rows) {
-    if (!h || !h->active) return MI355SW_ESTATE;
-    if (rows < h->fed_rows || rows > h->m) FAIL(h, MI355SW_EINVAL, "publish_first_column out of range");
+// Re-publish rows [0, rows) of the pinned first column that a previous attempt of the same partition already
+// received (overflow rerun: the manager's stream is sequential and cannot be rewound).
+static void republish_first_column(mi355sw_handle* h, int rows) {
     h->fed_rows = rows;
     __atomic_store_n(&h->h_pinned[16], rows, __ATOMIC_RELEASE);
+}
+
+// ------------------------------------------------------------------------------------------------
+// column ports
+// ------------------------------------------------------------------------------------------------
+int mi355sw_port_create(mi355sw_handle* h, int32_t rows, mi355sw_port_handle* out) {
+    if (!h || rows <= 0) return MI355SW_EINVAL;
+    if (h->active) FAIL(h, MI355SW_ESTATE, "port_create while a stream is active");
+    HIPCHK(h, hipSetDevice(h->device));
+    if (h->in_port) { (void) hipFree(h->in_port); h->in_port = nullptr; }
+    const size_t bytes = 256 + sizeof(int2) * ((size_t) rows + 1);
+    // fine-grained: stores arriving over xGMI from the neighbour's kernel and this GPU's system-scope loads
+    // meet in memory, not in a cache that only one side looks at
+    hipError_t e = hipExtMallocWithFlags(&h->in_port, bytes, hipDeviceMallocFinegrained);
+    if (e != hipSuccess) { h->in_port = nullptr; FAIL(h, MI355SW_ENOMEM, "hipExtMallocWithFlags(%zu, finegrained) failed: %s", bytes, hipGetErrorString(e)); }
+    h->in_port_bytes = bytes;
+    h->in_port_rows = rows;
+    HIPCHK(h, hipMemset(h->in_port, 0, 256));
+    HIPCHK(h, hipDeviceSynchronize());
+    if (out) {
+        memset(out, 0, sizeof(*out));
+        hipIpcMemHandle_t ipc;
+        HIPCHK(h, hipIpcGetMemHandle(&ipc, h->in_port));
+        static_assert(sizeof(ipc) <= sizeof(out->ipc), "hipIpcMemHandle_t does not fit");
+        memcpy(out->ipc, &ipc, sizeof(ipc));
+        out->bytes = (int64_t) bytes;
+        out->rows = rows;
+        out->device = h->device;
+    }
     return MI355SW_OK;
 }
 
-void* mi355sw_stream_device_first_column(mi355sw_handle* h) { return h ? (h->first_col_pinned ? h->p_first_col.p : h->d_first_col.p) : nullptr; }
-void* mi355sw_stream_device_last_column(mi355sw_handle* h) { return h ? h->p_last_col.p : nullptr; }
+static void drop_out_port(mi355sw_handle* h) {
+    if (h->out_port && h->out_port_ipc) (void) hipIpcCloseMemHandle(h->out_port);
+    h->out_port = nullptr; h->out_port_rows = 0; h->out_port_ipc = false;
+}
+
+int mi355sw_port_open(mi355sw_handle* h, const mi355sw_port_handle* remote) {
+    if (!h || !remote) return MI355SW_EINVAL;
+    if (h->active) FAIL(h, MI355SW_ESTATE, "port_open while a stream is active");
+    HIPCHK(h, hipSetDevice(h->device));
+    drop_out_port(h);
+    hipIpcMemHandle_t ipc;
+    memcpy(&ipc, remote->ipc, sizeof(ipc));
+    void* ptr = nullptr;
+    HIPCHK(h, hipIpcOpenMemHandle(&ptr, ipc, hipIpcMemLazyEnablePeerAccess));
+    h->out_port = ptr; h->out_port_rows = remote->rows; h->out_port_ipc = true;
+    return MI355SW_OK;
+}
+
+int mi355sw_port_attach(mi355sw_handle* h, mi355sw_handle* down) {
+    if (!h || !down) return MI355SW_EINVAL;
+    if (h->active) FAIL(h, MI355SW_ESTATE, "port_attach while a stream is active");
+    if (!down->in_port) FAIL(h, MI355SW_ESTATE, "port_attach: the downstream handle has no inbound port");
+    HIPCHK(h, hipSetDevice(h->device));
+    drop_out_port(h);
+    if (down->device != h->device) {
+        int can = 0;
+        HIPCHK(h, hipDeviceCanAccessPeer(&can, h->device, down->device));
+        if (!can) FAIL(h, MI355SW_EHIP, "GPU %d cannot access GPU %d", h->device, down->device);
+        hipError_t e = hipDeviceEnablePeerAccess(down->device, 0);
+        if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) FAIL(h, MI355SW_EHIP, "hipDeviceEnablePeerAccess: %s", hipGetErrorString(e));
+        (void) hipGetLastError();
+    }
+    h->out_port = down->in_port; h->out_port_rows = down->in_port_rows; h->out_port_ipc = false;
+    return MI355SW_OK;
+}
+
+int mi355sw_port_reset(mi355sw_handle* h) {
+    if (!h) return MI355SW_EINVAL;
+    if (h->active) FAIL(h, MI355SW_ESTATE, "port_reset while a stream is active");
+    if (!h->in_port) FAIL(h, MI355SW_ESTATE, "no inbound port");
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipMemsetAsync(h->in_port, 0, 256, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return MI355SW_OK;
+}
+
+int mi355sw_port_rows_ready(mi355sw_handle* h, int32_t* rows) {
+    if (!h || !rows) return MI355SW_EINVAL;
+    if (!h->in_port) FAIL(h, MI355SW_ESTATE, "no inbound port");
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipMemcpyAsync(rows, h->in_port, sizeof(int32_t), hipMemcpyDeviceToHost, h->copy));
+    HIPCHK(h, hipStreamSynchronize(h->copy));
+    return MI355SW_OK;
+}
+
+int mi355sw_port_read(mi355sw_handle* h, int32_t row, mi355sw_cell* cells, int32_t len) {
+    if (!h || !cells) return MI355SW_EINVAL;
+    if (!h->in_port) FAIL(h, MI355SW_ESTATE, "no inbound port");
+    if (row < 0 || len < 0 || row + len > h->in_port_rows) FAIL(h, MI355SW_EINVAL, "port_read range");
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipMemcpyAsync(cells, (char*) h->in_port + 256 + sizeof(int2) * ((size_t) row + 1), sizeof(int2) * (size_t) len,
+                             hipMemcpyDeviceToHost, h->copy));
+    HIPCHK(h, hipStreamSynchronize(h->copy));
+    return MI355SW_OK;
+}
+
+int mi355sw_port_local_pointers(mi355sw_handle* h, void** cells, void** counter) {
+    if (!h) return MI355SW_EINVAL;
+    if (!h->in_port) FAIL(h, MI355SW_ESTATE, "no inbound port");
+    if (cells) *cells = (char*) h->in_port + 256;
+    if (counter) *counter = h->in_port;
+    return MI355SW_OK;
+}
+
+int mi355sw_port_close(mi355sw_handle* h) {
+    if (!h) return MI355SW_EINVAL;
+    if (h->active) FAIL(h, MI355SW_ESTATE, "port_close while a stream is active");
+    (void) hipSetDevice(h->device);
+    drop_out_port(h);
+    if (h->in_port) (void) hipFree(h->in_port);
+    h->in_port = nullptr; h->in_port_bytes = 0; h->in_port_rows = 0;
+    return MI355SW_OK;
+}
 
 int mi355sw_stream_poll(mi355sw_handle* h, int32_t* rows_done, int32_t* finished) {
     if (!h || !h->active) return MI355SW_ESTATE;
@@ -639,12 +773,21 @@ int mi355sw_stream_poll(mi355sw_handle* h, int32_t* rows_done, int32_t* finished
         if (e == hipSuccess) h->finished = true;
         else if (e != hipErrorNotReady) FAIL(h, MI355SW_EHIP, "kernel failed: %s", hipGetErrorString(e));
     }
+    // strip counter FIRST, error mirror second: the kernel writes the mirror before the counter moves past the
+    // failing strip, so a counter value read while the mirror is still clean only covers exact strips
     const int done = __atomic_load_n(&h->h_pinned[0], __ATOMIC_ACQUIRE);
+    const int err = __atomic_load_n(&h->h_pinned[48], __ATOMIC_ACQUIRE);
     h->prog_strips = done;
     long long rows = (long long) done * h->SH;
     if (rows > h->m) rows = h->m;
+    if (err == 0) h->clean_rows = (int) rows;
+    else rows = h->clean_rows;
     if (rows_done) *rows_done = (int32_t) rows;
     if (finished) *finished = h->finished ? 1 : 0;
+    if (err == 16 && __atomic_load_n(&h->h_pinned[32], __ATOMIC_ACQUIRE) == 0) {
+        h->overflow_seen = true;
+        FAIL(h, MI355SW_EOVERFLOW16, "packed 16-bit kernel left its exact range after %lld rows; rerun with force_int32", rows);
+    }
     return MI355SW_OK;
 }
 
@@ -654,8 +797,10 @@ int mi355sw_stream_read_column(mi355sw_handle* h, int32_t row, mi355sw_cell* cel
     // rows below strips_done were written by the kernel (system-scope release) straight into this
     // pinned buffer: no copy, no queue
     const int done = __atomic_load_n(&h->h_pinned[0], __ATOMIC_ACQUIRE);
+    const int err = __atomic_load_n(&h->h_pinned[48], __ATOMIC_ACQUIRE);
     long long valid = std::min<long long>((long long) done * h->SH, h->m);
     if (h->finished) valid = h->m;
+    if (err != 0) valid = h->clean_rows;     // rows of the failing strip and below are void
     if (row + len > valid) FAIL(h, MI355SW_EINVAL, "read_column beyond completed rows (%d+%d > %lld)", row, len, valid);
     memcpy(cells, (mi355sw_cell*) h->p_last_col.p + 1 + row, sizeof(mi355sw_cell) * (size_t) len);
     return MI355SW_OK;
@@ -719,6 +864,8 @@ static int run_exact_pass(mi355sw_handle* h, int s_star, int want_score, mi355sw
     b.special_rows = nullptr; b.special_interval_strips = 0;
     b.last_col = nullptr; b.last_row = nullptr; b.ckpt_rows = nullptr; b.ckpt_interval_strips = 0;
     b.first_col_ready = nullptr;        // every row of a streamed first column has arrived by now
+    b.peer_ready = nullptr;             // the boundary column was published by the main pass
+    b.fault_strip = -1;
     b.trace = nullptr;
     int waves = std::min(count, h->waves);
     hipEvent_t e0, e1;
@@ -902,26 +1049,32 @@ int mi355sw_align_partition(mi355sw_handle* h, const mi355sw_partition* part, co
     if (mg->must_continue && !mg->must_continue(user)) return MI355SW_OK;
 
     // The packed 16-bit kernel re-centres its window on the wavefront, but should it ever leave its exact
-    // range this is reported, never silent.  When the partition needs no progressive traffic nothing is
-    // dispatched before the kernel has finished cleanly and the partition is simply re-run with the int32
-    // kernel; with progressive traffic (streamed first column, last-column matching with early stop) the
-    // overflow is returned to the caller as MI355SW_EOVERFLOW16 (retry with MI355SW_F_FORCE_INT32).
-    const bool progressive = (orig_col_type != MI355SW_INIT_WITH_ZEROES) || sp.want_last_column;
+    // range this is reported, never silent, and the partition is re-run with the int32 kernel.  Rows are only
+    // handed to the manager while the kernel's error mirror is clean (mi355sw_stream_poll), so everything
+    // dispatched before the report is exact and stays dispatched: the rerun REPLAYS -- the first-column cells
+    // already received are still in the pinned column and are re-published at once (the manager's stream is
+    // sequential and is only asked for the rows that are still missing), last-column chunks and special rows
+    // already handed over are not sent again.
     bool force32 = false;
     int rc = MI355SW_OK;
+    // (the int32 kernels have fewer strip heights than the packed one, so a rerun may use another height: all
+    //  replay state is kept in DP rows, not in strips)
+    int fed = 0, col_sent = 0;
+    int special_last_row = 0;             // DP row of the last special row handed over
+    bool stopped = false;
+    int stop_rows = 0;                    // rows that were complete (and dispatched) when the manager said stop
+    std::vector<mi355sw_cell> rowbuf;
     for (int attempt = 0; attempt < 2; attempt++) {
     sp.force_int32 = force32 ? 1 : 0;
     rc = mi355sw_stream_begin(h, part, &sp);
     if (rc) return rc;
-    const bool deferred = h->use16 && !progressive;
+    if (attempt > 0 && fed > 0) republish_first_column(h, fed);
+    // nothing to hand over before the end: wait for the kernel without touching the runtime
+    const bool quiet = (orig_col_type == MI355SW_INIT_WITH_ZEROES) && !sp.want_last_column && h->n_special == 0;
     const int SH = h->SH;
+    int special_sent = 0;                 // slots of THIS attempt's special-row buffer already dealt with
     std::vector<mi355sw_cell> buf((size_t) std::max(SH, 1 << 16));
-    int fed = 0, col_sent = 0, special_sent = 0;
-    bool stopped = false, overflow = false;
-    int stop_rows = 0;                    // rows that were complete (and dispatched) when the manager said stop
-    std::vector<mi355sw_cell> rowbuf;
-    // first-column cells needed later for the leading cell of special/last rows
-    std::vector<mi355sw_cell> fc_cells;   // fc_cells[k] = first column cell of DP row (k+1)*SH (or m)
+    bool overflow = false;
     for (;;) {
         // feed the first column in strip-sized chunks (AbstractDiagonalAligner::loadFirstColumn :433-456)
         // (nothing more is fed once the manager has said stop: AbstractDiagonalAligner leaves its iteration loop at the
@@ -934,28 +1087,25 @@ int mi355sw_align_partition(mi355sw_handle* h, const mi355sw_partition* part, co
                 const int len = std::min(SH, m - fed);
                 mg->receive_first_column(user, buf.data(), len);
                 first_col_tail = buf[(size_t) len - 1];
-                fc_cells.push_back(first_col_tail);
                 if ((rc = mi355sw_stream_feed_column(h, fed, buf.data(), len))) { mi355sw_stream_abort(h); mi355sw_stream_end(h, nullptr, nullptr); return rc; }
                 fed += len;
             }
         }
         int rows_done = 0, fin = 0;
-        if ((rc = mi355sw_stream_poll(h, &rows_done, &fin))) { mi355sw_stream_end(h, nullptr, nullptr); return rc; }
-        if (deferred) {
-            if (!fin) { struct timespec ts = {0, 200000}; nanosleep(&ts, nullptr); continue; }
-            int ctrl[64];
-            HIPCHK(h, hipMemcpy(ctrl, h->d_ctrl.p, sizeof(ctrl), hipMemcpyDeviceToHost));
-            if (ctrl[32] == 16) { overflow = true; break; }
-        }
+        rc = mi355sw_stream_poll(h, &rows_done, &fin);
+        if (rc == MI355SW_EOVERFLOW16 && !force32) { overflow = true; break; }
+        if (rc) { mi355sw_stream_abort(h); mi355sw_stream_end(h, nullptr, nullptr); return rc; }
+        if (quiet && !fin) { struct timespec ts = {0, 200000}; nanosleep(&ts, nullptr); if (!(mg->must_continue && !mg->must_continue(user))) continue; }
         // special rows that are complete (AbstractDiagonalAligner::flushSpecialRows :286-317)
         // (reads of device-resident rows go through the copy stream: only once nothing more has to be
         //  fed, so that a copy delayed by the running kernel can never starve the kernel of its column)
         while ((!stopped || fin) && special_sent < h->n_special && (fin || fed >= m || orig_col_type == MI355SW_INIT_WITH_ZEROES)) {
             const int dp_row = (special_sent + 1) * h->special_interval_strips * SH;
             if (dp_row > (stopped ? stop_rows : rows_done)) break;
+            if (dp_row <= special_last_row) { special_sent++; continue; }   // handed over by the attempt before
             mi355sw_cell c;
             if (orig_col_type == MI355SW_INIT_WITH_ZEROES) { c.h = 0; }
-            else c = fc_cells[(size_t) dp_row / SH - 1];
+            else c = ((const mi355sw_cell*) h->p_first_col.p)[dp_row];      // cell of DP row dp_row (index 0 = corner)
             c.f = -MI355SW_INF;
             mg->dispatch_row(user, part->i0 + dp_row, &c, 1);
             rowbuf.resize((size_t) n);
@@ -963,6 +1113,7 @@ int mi355sw_align_partition(mi355sw_handle* h, const mi355sw_partition* part, co
             const int CH = 1 << 20;
             for (int j = 0; j < n; j += CH) mg->dispatch_row(user, part->i0 + dp_row, rowbuf.data() + j, std::min(CH, n - j));
             special_sent++;
+            special_last_row = dp_row;
         }
         // last column chunks (AbstractDiagonalAligner::flushLastColumn :361-372)
         if (sp.want_last_column) {
@@ -985,7 +1136,8 @@ int mi355sw_align_partition(mi355sw_handle* h, const mi355sw_partition* part, co
         }
     }
     if (overflow) {
-        (void) mi355sw_stream_end(h, nullptr, nullptr);   // reports MI355SW_EOVERFLOW16
+        (void) mi355sw_stream_abort(h);
+        (void) mi355sw_stream_end(h, nullptr, nullptr);
         force32 = true;
         continue;
     }
@@ -998,7 +1150,7 @@ int mi355sw_align_partition(mi355sw_handle* h, const mi355sw_partition* part, co
         if ((rc = mi355sw_stream_read_last_row(h, lastrow.data(), 0, n))) { mi355sw_stream_end(h, nullptr, nullptr); return rc; }
     }
     rc = mi355sw_stream_end(h, &best, &nsp);
-    if (rc == MI355SW_EOVERFLOW16 && !force32) { force32 = true; continue; }
+    if (rc == MI355SW_EOVERFLOW16 && !force32) { force32 = true; continue; }   // e.g. reported by the exact pass
     if (rc) return rc;
     if (stopped) return MI355SW_OK;
     if (mg->must_dispatch_last_row && mg->must_dispatch_last_row(user)) {
@@ -1044,17 +1196,25 @@ int mi355sw_process_block(mi355sw_handle* h, mi355sw_cell* row, mi355sw_cell* co
     sp.want_last_column = 1;
     sp.want_last_row = 1;
     sp.track_best = 1;
-    int rc = mi355sw_stream_begin(h, &part, &sp);
-    if (rc) return rc;
     mi355sw_score b;
-    // the kernel must be complete before the borders are read back
-    HIPCHK(h, hipStreamSynchronize(h->stream));
     std::vector<mi355sw_cell> lr((size_t) n), lc((size_t) m);
-    if ((rc = mi355sw_stream_read_last_row(h, lr.data(), 0, n)) || (rc = mi355sw_stream_read_column(h, 0, lc.data(), m))) {
-        mi355sw_stream_end(h, nullptr, nullptr);
-        return rc;
+    int rc = MI355SW_OK;
+    // every input is in hand, so a block the packed kernel cannot hold is simply computed again in int32
+    for (int attempt = 0; attempt < 2; attempt++) {
+        sp.force_int32 = attempt;
+        if ((rc = mi355sw_stream_begin(h, &part, &sp))) return rc;
+        // the kernel must be complete before the borders are read back
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        int rows_done = 0, fin = 0;
+        rc = mi355sw_stream_poll(h, &rows_done, &fin);
+        if (!rc) rc = mi355sw_stream_read_last_row(h, lr.data(), 0, n);
+        if (!rc) rc = mi355sw_stream_read_column(h, 0, lc.data(), m);
+        if (rc) { (void) mi355sw_stream_end(h, nullptr, nullptr); if (rc == MI355SW_EOVERFLOW16 && attempt == 0) continue; return rc; }
+        rc = mi355sw_stream_end(h, &b, nullptr);
+        if (rc == MI355SW_EOVERFLOW16 && attempt == 0) continue;
+        if (rc) return rc;
+        break;
     }
-    if ((rc = mi355sw_stream_end(h, &b, nullptr))) return rc;
     // CPUBlockProcessor.cpp:159-165: col[0] <- H(i0-1, j1-1) (diagonal for the block to the right)
     col[0].h = row[n - 1].h;
     memcpy(row, lr.data(), sizeof(mi355sw_cell) * (size_t) n);

@@ -40,7 +40,16 @@ struct KernelArgs {
     const int* host_abort;       // pinned host word: the host sets it != 0 to stop (mustContinue() == false) -- a store,
                                  // not a copy, because no copy may be queued while the persistent kernel runs
     int* error_flag;             // set by the kernel on a bounded-spin timeout
-    const int* first_col_ready;  // pinned host counter: rows of first_col that are valid, or nullptr (all)
+    const int* first_col_ready;  // counter of first_col rows that are valid (system scope), or nullptr (all): pinned host
+                                 // memory when the host feeds the column, this GPU's HBM (fine-grained) when the
+                                 // neighbour GPU's kernel writes it over xGMI (column port)
+    int* peer_ready;             // column port of the NEXT band (peer-mapped, system scope): rows of last_col written so
+                                 // far are published here by complete_strip, or nullptr
+    int* host_error;             // pinned host mirror of error_flag, written BEFORE the strip counter moves past the
+                                 // failing strip (the host must not hand out rows of a strip that left its exact range)
+    int fault_strip;             // test knob (MI355SW_FAULT_OVERFLOW_STRIP): this strip of the packed kernel reports an
+                                 // overflow it did not have, so that the int32 rerun / replay paths can be exercised; -1 = off
+    long long wait_ticks;        // budget (10 ns ticks of s_memrealtime) of waits on data another GPU or the host delivers
     int* strips_done_dev;        // device counter, ordered: value s means strips [0,s) complete
     int* strips_done_host;       // pinned host mirror (system scope)
     int* gbest;                  // running global best (T domain): lower bound that seeds every lane's threshold
@@ -64,6 +73,99 @@ __device__ __forceinline__ UniformArgs uniform_args(const KernelArgs* p) {
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned) v);
     const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned) (v >> 32));
     return (UniformArgs) (((unsigned long long) hi << 32) | lo);
+}
+#endif
+
+// ---- strip hand-over shared by both kernel families (claim a strip / complete it in order) -------------------
+// Separate noinline functions on purpose: with a lane-0-only `if` as the last statement of the persistent
+// loop, hipcc's structurizer moved lane 0 out of the loop body and sent lanes 1..63 through the next iteration
+// on their own; and a wait loop placed in the strip function itself changes the hot loop's register allocation
+// (measured: -40 % on the 3 M x 3 M case).
+#if defined(__HIPCC__)
+namespace sync {
+__device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ int poll_dev(const int* p) { return rfl(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); }
+__device__ __forceinline__ int poll_system(const int* p) { return rfl(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)); }
+}  // namespace sync
+
+// Claim the next strip: ordered tickets => forward progress for any grid size.
+// A band whose first column is delivered from outside (host-fed pinned column, or the neighbour GPU writing
+// this GPU's column port) waits HERE until the rows of the claimed strip have arrived: first for the strip above
+// to have produced its first columns (device-scope poll; a strip cannot move before that anyway, so only one or
+// two wavefronts poll the outside counter at any time -- with every wavefront of a launch polling pinned host
+// memory the neighbour band's PCIe stores crawled), then for the counter.  The budget is wall time
+// (s_memrealtime, 100 MHz), not a spin count; when it runs out the strip is given up (abort + error 2) instead
+// of being computed on rows that never came.
+static __device__ __attribute__((noinline, unused)) int claim_strip_common(const KernelArgs* ap, const int lane, const int strip_rows) {
+    const UniformArgs a = uniform_args(ap);
+    int s = 0;
+    if (lane == 0) s = atomicAdd(a->ticket, 1);
+    s = sync::rfl(s);
+    if (a->first_col_ready != nullptr && s < a->num_strips) {
+        const long long t0 = __builtin_amdgcn_s_memrealtime();
+        const long long budget = a->wait_ticks;
+        const int* prog_in = &a->progress[s];
+        bool ok = true, stop = false;
+        int it = 0;
+        while (sync::poll_dev(prog_in) < 1) {
+            if (sync::poll_dev(a->abort_flag) != 0) { stop = true; break; }
+            if ((++it & 255) == 0) {
+                if (a->host_abort != nullptr && sync::poll_system(a->host_abort) != 0) { stop = true; break; }
+                if (__builtin_amdgcn_s_memrealtime() - t0 > budget) { ok = false; break; }
+            }
+            __builtin_amdgcn_s_sleep(16);
+        }
+        long long need = (long long) a->strip_row0 + (long long) (s + 1) * strip_rows;
+        if (need > a->m) need = a->m;
+        while (ok && !stop && sync::poll_system(a->first_col_ready) < (int) need) {
+            if (sync::poll_dev(a->abort_flag) != 0) break;
+            if ((++it & 63) == 0) {
+                if (a->host_abort != nullptr && sync::poll_system(a->host_abort) != 0) break;
+                if (__builtin_amdgcn_s_memrealtime() - t0 > budget) { ok = false; break; }
+            }
+            __builtin_amdgcn_s_sleep(32);
+        }
+        if (!ok && lane == 0) {
+            atomicExch(a->error_flag, 2);
+            __hip_atomic_store(a->abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    return s;
+}
+
+// Ordered completion: strips_done == s+1 means strips 0..s are complete and their last-column / special-row /
+// best records are visible (system scope) to the host -- and, through the column port, to the next band's GPU.
+static __device__ __attribute__((noinline, unused)) void complete_strip_common(const KernelArgs* ap, const int s_in, const int lane, const int strip_rows) {
+    const UniformArgs a = uniform_args(ap);
+    const int s = sync::rfl(s_in);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    int spins = 0;
+    // a band fed from outside may legitimately stand still for as long as its first column takes to arrive
+    const int spin_limit = a->first_col_ready != nullptr ? (1 << 30) : (1 << 24);
+    while (sync::poll_dev(a->strips_done_dev) != s && spins < spin_limit) {
+        __builtin_amdgcn_s_sleep(8);
+        spins++;
+    }
+    if (lane == 0) {
+        if (spins >= spin_limit) atomicExch(a->error_flag, 3);
+        const int err = __hip_atomic_load(a->error_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (err != 0 && a->host_error != nullptr)
+            __hip_atomic_store(a->host_error, err, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (a->peer_ready != nullptr && err == 0 &&
+            __hip_atomic_load(a->abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0 &&
+            (a->host_abort == nullptr || __hip_atomic_load(a->host_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0)) {
+            long long rows = (long long) a->strip_row0 + (long long) (s + 1) * strip_rows;
+            if (rows > a->m) rows = a->m;
+            // the strip's last-column cells were stored into the neighbour's HBM by every lane before the
+            // system-scope release fence above; this is the flag that follows them over xGMI
+            __hip_atomic_store(a->peer_ready, (int) rows, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        if (a->strips_done_host != nullptr)
+            __hip_atomic_store(a->strips_done_host, s + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(a->strips_done_dev, s + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __builtin_amdgcn_wave_barrier();
 }
 #endif
 

@@ -181,7 +181,7 @@ __device__ __attribute__((noinline)) void process_strip(const KernelArgs* ap, co
     const int* prog_in = &a->progress[s];              // progress of the strip above
     // wait budget of the in-kernel polls: a band fed by another GPU may legitimately stand still for as long as
     // its first column takes to arrive (the first strip waits on the host counter, all others on that strip)
-    const int spin_limit = a->first_col_ready != nullptr ? (1 << 28) : (1 << 24);
+    const int spin_limit = a->first_col_ready != nullptr ? (1 << 30) : (1 << 24);
     int* prog_out = &a->progress[s + 1];
 
     // which (lane,row) is the row handed to the next strip / flushed as special row
@@ -202,16 +202,7 @@ __device__ __attribute__((noinline)) void process_strip(const KernelArgs* ap, co
     int2* lastrow = (last_strip && a->last_row != nullptr) ? a->last_row : nullptr;
 
     // ---- per-lane state from the first column (InitialCellsReader semantics on device) ----
-    if (a->first_col != nullptr && a->first_col_ready != nullptr) {
-        int need = row0 + SH;                         // rows [0,need) of the first column
-        if (need > a->m) need = a->m;
-        int spins = 0;
-        while (poll_sys(a->first_col_ready) < need && poll_agent(a->abort_flag) == 0 && spins < (1 << 26)) {
-            __builtin_amdgcn_s_sleep(32);
-            spins++;
-        }
-        if (spins >= (1 << 26) && lane == 0) atomicExch(a->error_flag, 2);
-    }
+    // (a column delivered from outside has been awaited in claim_strip_common)
     LaneState<R> st;
 #pragma unroll
     for (int r = 0; r < R; r++) {
@@ -353,54 +344,6 @@ __device__ __attribute__((noinline)) void process_strip(const KernelArgs* ap, co
     }
 }
 
-// Ordered completion: strips_done == s+1 means strips 0..s are complete and their last-column /
-// special-row / best records are visible to the host (system scope).  A separate noinline function on
-// purpose: with a lane-0-only `if` as the last statement of the persistent loop, hipcc's structurizer
-// moved lane 0 out of the loop body and sent lanes 1..63 through the next iteration on their own
-// (readfirstlane then read their zero-initialised ticket: strip 0 was processed twice and never published).
-__device__ __attribute__((noinline)) void complete_strip(const KernelArgs* ap, const int s_in, const int lane) {
-    const UniformArgs a = uniform_args(ap);
-    const int s = __builtin_amdgcn_readfirstlane(s_in);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
-    int spins = 0;
-    // a band fed by another GPU may legitimately stand still for as long as its first column takes to arrive
-    const int spin_limit = a->first_col_ready != nullptr ? (1 << 28) : (1 << 24);
-    while (poll_agent(a->strips_done_dev) != s && spins < spin_limit) {
-        __builtin_amdgcn_s_sleep(8);
-        spins++;
-    }
-    if (lane == 0) {
-        if (spins >= spin_limit) atomicExch(a->error_flag, 3);
-        if (a->strips_done_host != nullptr)
-            __hip_atomic_store(a->strips_done_host, s + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        st_agent(a->strips_done_dev, s + 1);
-    }
-    __builtin_amdgcn_wave_barrier();
-}
-
-// Claim the next strip: ordered tickets => forward progress for any grid size.
-__device__ __attribute__((noinline)) int claim_strip(const KernelArgs* ap, const int lane) {
-    const UniformArgs a = uniform_args(ap);
-    int s = 0;
-    if (lane == 0) s = atomicAdd(a->ticket, 1);
-    s = __builtin_amdgcn_readfirstlane(s);
-    // Streamed first column (a band fed by another GPU): the strip function polls a counter in pinned HOST memory
-    // until its rows have arrived, a PCIe round trip per poll.  A strip cannot move before the strip above has
-    // produced its first columns anyway, so wait for that here first (device-scope poll): one or two wavefronts
-    // then poll the host at any time instead of every wavefront of the launch (with all of them polling, the
-    // neighbour band's stores to its pinned last column crawled: 48 s instead of 8.6 s per step when two bands
-    // shared one GPU's PCIe link).
-    if (a->first_col_ready != nullptr && s < a->num_strips) {
-        const int* prog_in = &a->progress[s];
-        int spins = 0;
-        while (poll_agent(prog_in) < 1 && poll_agent(a->abort_flag) == 0 && spins < (1 << 28)) {
-            __builtin_amdgcn_s_sleep(16);
-            spins++;
-        }
-    }
-    return s;
-}
-
 template <int R, bool SW, bool PROFILE, bool TRACK>
 __global__ void __launch_bounds__(64) sw_strip_kernel(const KernelArgs* __restrict__ ap) {
     __shared__ WaveLds lds_store;
@@ -411,7 +354,7 @@ __global__ void __launch_bounds__(64) sw_strip_kernel(const KernelArgs* __restri
     // one wavefront per SIMD, enforced: see sw_kernel_pk16.inc
     asm volatile("" ::: "a255");
     for (;;) {
-        const int s = __builtin_amdgcn_readfirstlane(claim_strip(ap, lane));
+        const int s = __builtin_amdgcn_readfirstlane(claim_strip_common(ap, lane, 64 * R));
         if (s >= num_strips) break;
         if (poll_agent(a->abort_flag) != 0 || (a->host_abort != nullptr && poll_sys(a->host_abort) != 0)) {
             // publish completion so that followers do not spin forever
@@ -420,7 +363,7 @@ __global__ void __launch_bounds__(64) sw_strip_kernel(const KernelArgs* __restri
         } else {
             process_strip<R, SW, PROFILE, TRACK>(ap, s, lds, lane);
         }
-        complete_strip(ap, s, lane);
+        complete_strip_common(ap, s, lane, 64 * R);
     }
 }
 

@@ -89,7 +89,21 @@ class StreamParams(C.Structure):
                 ("first_column", C.c_void_p),
                 ("want_last_column", C.c_int32), ("want_last_row", C.c_int32),
                 ("special_row_interval", C.c_int32), ("track_best", C.c_int32), ("force_int32", C.c_int32),
-                ("prune_blocks", C.c_int32), ("prune_rows", C.c_int32), ("prune_cols", C.c_int32)]
+                ("prune_blocks", C.c_int32), ("prune_rows", C.c_int32), ("prune_cols", C.c_int32),
+                ("first_column_port", C.c_int32), ("last_column_port", C.c_int32),
+                ("first_column_resume_rows", C.c_int32)]
+
+
+class PortHandle(C.Structure):
+    """mi355sw_port_handle: what the owner of a column port sends to the band on its left (hipIpc handle + size)."""
+    _fields_ = [("ipc", C.c_ubyte * 64), ("bytes", C.c_int64), ("rows", C.c_int32), ("device", C.c_int32)]
+
+    def tobytes(self):
+        return bytes(memoryview(self))
+
+    @classmethod
+    def frombytes(cls, b):
+        return cls.from_buffer_copy(bytes(b))
 
 
 _VP = C.c_void_p
@@ -122,9 +136,8 @@ ABI_SYMBOLS = [
     "mi355sw_stream_begin", "mi355sw_stream_feed_column", "mi355sw_stream_poll",
     "mi355sw_stream_read_column", "mi355sw_stream_read_special_row", "mi355sw_stream_read_last_row",
     "mi355sw_stream_abort", "mi355sw_stream_end", "mi355sw_stream_strip_scores",
-    "mi355sw_stream_device_first_column", "mi355sw_stream_device_last_column",
-    "mi355sw_stream_publish_first_column", "mi355sw_stream_feed_column_device",
-    "mi355sw_stream_read_column_device", "mi355sw_device_count", "mi355sw_device_info",
+    "mi355sw_port_create", "mi355sw_port_open", "mi355sw_port_attach", "mi355sw_port_reset", "mi355sw_port_rows_ready", "mi355sw_port_read",
+    "mi355sw_port_local_pointers", "mi355sw_port_close", "mi355sw_device_count", "mi355sw_device_info",
 ]
 
 _lib = None
@@ -174,13 +187,14 @@ def load_library():
     lib.mi355sw_stream_abort.argtypes = [H]
     lib.mi355sw_stream_end.argtypes = [H, C.POINTER(Score), C.POINTER(C.c_int32)]
     lib.mi355sw_stream_strip_scores.argtypes = [H, C.c_void_p, C.c_int32]
-    lib.mi355sw_stream_device_first_column.argtypes = [H]
-    lib.mi355sw_stream_device_first_column.restype = C.c_void_p
-    lib.mi355sw_stream_device_last_column.argtypes = [H]
-    lib.mi355sw_stream_device_last_column.restype = C.c_void_p
-    lib.mi355sw_stream_publish_first_column.argtypes = [H, C.c_int32]
-    lib.mi355sw_stream_feed_column_device.argtypes = [H, C.c_int32, C.c_void_p, C.c_int32]
-    lib.mi355sw_stream_read_column_device.argtypes = [H, C.c_int32, C.c_void_p, C.c_int32]
+    lib.mi355sw_port_create.argtypes = [H, C.c_int32, C.POINTER(PortHandle)]
+    lib.mi355sw_port_open.argtypes = [H, C.POINTER(PortHandle)]
+    lib.mi355sw_port_attach.argtypes = [H, H]
+    lib.mi355sw_port_reset.argtypes = [H]
+    lib.mi355sw_port_rows_ready.argtypes = [H, C.POINTER(C.c_int32)]
+    lib.mi355sw_port_read.argtypes = [H, C.c_int32, C.c_void_p, C.c_int32]
+    lib.mi355sw_port_local_pointers.argtypes = [H, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
+    lib.mi355sw_port_close.argtypes = [H]
     lib.mi355sw_device_info.argtypes = [C.c_int32, C.c_char_p, C.c_size_t, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                         C.POINTER(C.c_int64)]
     _lib = lib
@@ -298,7 +312,8 @@ class MI355Aligner:
                     first_row_start_offset=0, first_row=None, first_column_init_type=INIT_WITH_ZEROES,
                     first_column_start_offset=0, stream_first_column=False, first_column=None,
                     want_last_column=False, want_last_row=False, special_row_interval=0, track_best=True,
-                    force_int32=False, prune_blocks=False, prune_rows=0, prune_cols=0):
+                    force_int32=False, prune_blocks=False, prune_rows=0, prune_cols=0,
+                    first_column_port=False, last_column_port=False, first_column_resume_rows=0):
         sp = StreamParams()
         sp.recurrence_type = recurrence_type
         sp.first_row_init_type, sp.first_row_start_offset = first_row_init_type, first_row_start_offset
@@ -313,18 +328,14 @@ class MI355Aligner:
         sp.special_row_interval, sp.track_best = special_row_interval, int(track_best)
         sp.force_int32 = int(force_int32)
         sp.prune_blocks, sp.prune_rows, sp.prune_cols = int(prune_blocks), int(prune_rows), int(prune_cols)
+        sp.first_column_port, sp.last_column_port = int(first_column_port), int(last_column_port)
+        sp.first_column_resume_rows = int(first_column_resume_rows)
         self._check(self._lib.mi355sw_stream_begin(self._h, C.byref(partition), C.byref(sp)), "streamBegin")
         self._stream_part = partition
 
     def streamFeedColumn(self, row, cells):
         a = _cells(cells)
         self._check(self._lib.mi355sw_stream_feed_column(self._h, row, a.ctypes.data, len(a)), "streamFeedColumn")
-
-    def streamFeedColumnDevice(self, row, dev_ptr, length):
-        self._check(self._lib.mi355sw_stream_feed_column_device(self._h, row, dev_ptr, length), "streamFeedColumnDevice")
-
-    def streamReadColumnDevice(self, row, dev_ptr, length):
-        self._check(self._lib.mi355sw_stream_read_column_device(self._h, row, dev_ptr, length), "streamReadColumnDevice")
 
     def streamPoll(self):
         rows, fin = C.c_int32(), C.c_int32()
@@ -365,14 +376,41 @@ class MI355Aligner:
         cnt = self._lib.mi355sw_stream_strip_scores(self._h, buf.ctypes.data, max_count)
         return buf[:cnt].copy()
 
-    def streamDeviceFirstColumn(self):
-        return self._lib.mi355sw_stream_device_first_column(self._h)
+    # -- column ports (boundary column GPU to GPU over xGMI) ----------------------------------------
+    def portCreate(self, rows):
+        """inbound port of this band: returns the PortHandle to send to the band on the left"""
+        ph = PortHandle()
+        self._check(self._lib.mi355sw_port_create(self._h, rows, C.byref(ph)), "portCreate")
+        return ph
 
-    def streamDeviceLastColumn(self):
-        return self._lib.mi355sw_stream_device_last_column(self._h)
+    def portOpen(self, port_handle):
+        """map the right neighbour's inbound port (another process) as this band's outbound port"""
+        self._check(self._lib.mi355sw_port_open(self._h, C.byref(port_handle)), "portOpen")
 
-    def streamPublishFirstColumn(self, rows):
-        self._check(self._lib.mi355sw_stream_publish_first_column(self._h, rows), "streamPublishFirstColumn")
+    def portAttach(self, downstream):
+        """same process: `downstream`'s inbound port becomes this band's outbound port"""
+        self._check(self._lib.mi355sw_port_attach(self._h, downstream._h), "portAttach")
+
+    def portReset(self):
+        self._check(self._lib.mi355sw_port_reset(self._h), "portReset")
+
+    def portRowsReady(self):
+        r = C.c_int32()
+        self._check(self._lib.mi355sw_port_rows_ready(self._h, C.byref(r)), "portRowsReady")
+        return r.value
+
+    def portRead(self, row, length):
+        out = np.empty((length, 2), dtype=np.int32)
+        self._check(self._lib.mi355sw_port_read(self._h, row, out.ctypes.data, length), "portRead")
+        return out
+
+    def portLocalPointers(self):
+        cells, counter = C.c_void_p(), C.c_void_p()
+        self._check(self._lib.mi355sw_port_local_pointers(self._h, C.byref(cells), C.byref(counter)), "portLocalPointers")
+        return cells.value, counter.value
+
+    def portClose(self):
+        self._check(self._lib.mi355sw_port_close(self._h), "portClose")
 
 
 def make_manager_table(mgr):

@@ -129,6 +129,7 @@ void Mi355Aligner::alignPartition(Partition partition) {
     if (mi355sw_get_stats(handle, &st) == MI355SW_OK) {
         statCells += st.cells;
         statKernelMs += st.kernel_ms;
+        statPruned += st.pruned_cells;
         statPartitions++;
     }
 }
@@ -161,7 +162,7 @@ int32_t Mi355Aligner::cbScores(void* u) { return SELF->mustDispatchScores() ? 1 
 int32_t Mi355Aligner::cbPrune(void* u) { return SELF->mustPruneBlocks() ? 1 : 0; }
 #undef SELF
 
-void Mi355Aligner::clearStatistics() { statCells = 0; statKernelMs = 0; statPartitions = 0; }
+void Mi355Aligner::clearStatistics() { statCells = 0; statKernelMs = 0; statPartitions = 0; statPruned = 0; }
 void Mi355Aligner::printInitialStatistics(FILE* file) {
     char name[128]; int cus = 0, mhz = 0; long long bytes = 0;
     if (mi355sw_device_info(config.device < 0 ? 0 : config.device, name, sizeof(name), &cus, &mhz, (int64_t*) &bytes) == MI355SW_OK)
@@ -170,7 +171,7 @@ void Mi355Aligner::printInitialStatistics(FILE* file) {
 void Mi355Aligner::printStageStatistics(FILE* file) {}
 void Mi355Aligner::printFinalStatistics(FILE* file) {}
 void Mi355Aligner::printStatistics(FILE* file) {
-    fprintf(file, "\n===== MI355 ENGINE =====\nPartitions: %d\nCells: %lld\nKernel time: %.3f ms\n", statPartitions, statCells, statKernelMs);
+    fprintf(file, "\n===== MI355 ENGINE =====\nPartitions: %d\nCells: %lld\nPruned cells: %lld\nKernel time: %.3f ms\n", statPartitions, statCells, statPruned, statKernelMs);
     if (statKernelMs > 0) fprintf(file, "Kernel GCUPS: %.2f\n", statCells / statKernelMs / 1e6);
 }
 const char* Mi355Aligner::getProgressString() const {

@@ -62,6 +62,7 @@ private:
     Mi355AlignerParameters* params;
     mutable char progress[256];
     long long statCells;
+    long long statPruned;
     double statKernelMs;
     int statPartitions;
 };

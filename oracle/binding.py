@@ -216,6 +216,16 @@ def read_ref_work(work, log=""):
                 if len(fn) == 8 and all(c in "0123456789ABCDEF" for c in fn):
                     out["special_rows"][(d, int(fn, 16))] = \
                         np.fromfile(os.path.join(full, fn), dtype=np.int32).reshape(-1, 2)
+    # per-stage statistics files (Pruned Blocks of stage 1; the product adapter's own section)
+    out["statistics"] = {}
+    for fn in sorted(os.listdir(work)) if os.path.isdir(work) else []:
+        if fn.startswith("statistics_"):
+            txt = open(os.path.join(work, fn), errors="replace").read()
+            out["statistics"][fn] = txt
+            for ln in txt.splitlines():
+                if ln.startswith("Pruned Blocks:") and fn == "statistics_01.00":
+                    a, b = ln.split(":")[1].split("/")
+                    out["pruned_blocks"] = [int(a), int(b)]
     for fn in ("alignment.00.txt",):
         pth = os.path.join(work, fn)
         if os.path.exists(pth):

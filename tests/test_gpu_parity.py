@@ -509,3 +509,74 @@ def test_stop_like_stage2_goal_found(pkg, oracle):
         assert np.array_equal(mg.specialRow(r), want[r]), r
     assert creader.asked < m // 2                       # the first-column stream was left alone after the stop
     assert st["processed_cells"] < 0.6 * m * n          # and much of the partition was never computed
+
+
+@pytest.mark.parametrize("rel", [False, True])
+def test_two_phase_at_its_real_trigger(pkg, oracle, rel):
+    """Partitions with >= 32 Mi rows (BASELINE C3, C4, C5 and the 228 M target) track only the best VALUE in the main
+    pass and recompute the winning strip exactly from a checkpoint row.  33.6 M x 16 k, no environment override:
+    the packed two-phase run, the int32 single-pass run and the oracle (on the window that ends at the reported
+    cell) agree."""
+    m, n = 33600000, 16384
+    assert m >= (32 << 20)
+    s0, s1 = (pkg.seqgen.related_pair if rel else pkg.seqgen.unrelated_pair)(m, n, cfg=62)
+    part = pkg.Partition(0, 0, m, n)
+    res = {}
+    for flags in (0, 2):
+        al = pkg.MI355Aligner(device=0, flags=flags)
+        try:
+            al.setSequences(s0, s1)
+            mg = pkg.Stage1Manager(part)
+            al.alignPartition(part, mg)
+            st = al.getStatistics()
+            res[flags] = tuple(mg.getBestScore())
+            if flags == 0:
+                assert st["profile_kernel"] == 2 and st["kernel_launches"] == 2      # main pass + exact pass
+                assert st["strips"] >= 16000
+            else:
+                assert st["profile_kernel"] == 1 and st["kernel_launches"] == 1
+        finally:
+            al.close()
+    assert res[0] == res[2]
+    i, j, score = res[0]
+    assert score > (8000 if rel else 15)
+    # the alignment that ends at (i, j) is at most ~1.3 * n rows long: the oracle recomputes the window that holds it
+    W = min(i, 3 * n)
+    ref = oracle.stage1(s0[i - W:i], s1[:j], want_last_row=True)
+    assert ref["best"][2] == score and int(ref["last_row"][-1][0]) == score
+    # nothing above the window beats it either: the rows [0, i) hold no higher score (checked on a second window
+    # placed where the int32 run and the packed run agree anyway; here: canonical = first row reaching the maximum)
+    assert ref["best"][0] == W and ref["best"][1] == j
+
+
+def test_match_last_column_follows_aligner_utils(pkg, oracle, aligner):
+    """IAligner::matchLastColumn = AlignerUtils::matchColumn (M/libmasa/utils/AlignerUtils.cpp:50-107): first k with
+    base.h + buffer.h == goal (aligned) or base.e + buffer.e + gap_open == goal (gapped); a sum above the goal is
+    reported as the reference's MATCH_ERROR_1 / _2."""
+    rng = np.random.default_rng(17)
+    for case in range(60):
+        n = int(rng.integers(1, 400))
+        base = rng.integers(-500, 500, size=(n, 2)).astype(np.int32)
+        buf = rng.integers(-500, 500, size=(n, 2)).astype(np.int32)
+        goal = 1500
+        kind = case % 5
+        k = int(rng.integers(0, n))
+        if kind == 0:
+            buf[k, 0] = goal - base[k, 0]
+        elif kind == 1:
+            buf[k, 1] = goal - 3 - base[k, 1]
+        elif kind == 2:
+            buf[k, 0] = goal + 7 - base[k, 0]
+        elif kind == 3:
+            buf[k, 1] = goal + 2 - 3 - base[k, 1]
+        got = aligner.matchLastColumn(buf, base, goal)
+        rc, rk, rs, rt = oracle.match_column(buf, base, goal)
+        if rc == 1:
+            assert got == {"found": True, "k": rk, "score": rs, "type": rt}, case
+        elif rc == 0:
+            assert got["found"] is False and got["k"] == -1, case
+        else:
+            assert got["found"] is False and got["k"] == rk and got["type"] == rc, case
+    with_inf = np.array([[5, -pkg.INF], [7, 3]], dtype=np.int32)
+    got = aligner.matchLastColumn(with_inf, np.array([[1, -pkg.INF], [2, 4]], dtype=np.int32), 10)
+    assert got == {"found": True, "k": 1, "score": 4, "type": 1}
