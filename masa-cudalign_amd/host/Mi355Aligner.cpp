@@ -19,7 +19,11 @@ Mi355Aligner::Mi355Aligner(int device, int rowsPerLane, int waves) : handle(NULL
     score_params.gap_ext = sp.gap_ext;
     params = new Mi355AlignerParameters();
     if (device >= 0) params->setGPU(device);
-    setForkCount(1);
+    // one forked instance per GPU, seq1 split in proportion to compute units x clock (X/CUDAligner.cpp:63-66)
+    int weights[64];
+    const int gpus = Mi355AlignerParameters::deviceWeights(weights, 64);
+    if (gpus > 0) setForkCount(gpus, weights);
+    else setForkCount(1);
     clearStatistics();
     progress[0] = 0;
 }
@@ -83,6 +87,10 @@ void Mi355Aligner::initialize() {
         params->setGPU(id);
     }
     if (params->getGPU() == MI355_DETECT_FASTEST_GPU) params->setGPU(Mi355AlignerParameters::fastestGPU());
+    if (params->getGPU() >= mi355sw_device_count()) {     // --gpu is validated here, after any fork (see processArgument)
+        fprintf(stderr, "Mi355Aligner: GPU index %d out of range, %d device(s) (see --list-gpus).\n", params->getGPU(), mi355sw_device_count());
+        exit(2);
+    }
     config.device = params->getGPU();
     if (params->getWaves() > 0) config.waves = params->getWaves();
     if (params->getStripRows() > 0) config.rows_per_lane = params->getStripRows() / 64;

@@ -4,18 +4,22 @@
 #include <getopt.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <sys/types.h>
+#include <sys/wait.h>
+#include <unistd.h>
 
 #include "mi355sw.h"
 
 #define USAGE "\
---gpu=GPU               Selects the index of the GPU used for the computation. If  \n\
-                           GPU is not informed, the fastest GPU is selected.   \n\
-                           A list of available GPUs can be obtained with the   \n\
-                           --list-gpus parameter. \n\
---list-gpus             Lists all available GPUs. \n\
---blocks=B              Run B strip wavefronts (default: one per SIMD of the GPU)\n\
---strip-rows=R          Rows of one strip: 256, 512, 768, 1024, 1536 or 2048\n\
-                           (default: chosen per partition by the engine's cost model)\n\
+--gpu=INDEX             Run on the MI355X with this HIP device index (see --list-gpus).\n\
+                           Without it the device with the most compute units x clock is\n\
+                           taken; a forked instance takes the device of its fork id.\n\
+--list-gpus             Print the gfx950 devices this extension can use, then exit.\n\
+--blocks=B              Keep B strip wavefronts resident (default: one per SIMD).\n\
+--strip-rows=R          Height of a strip in DP rows: 256, 512, 768, 1024, 1536 or 2048\n\
+                           (default: picked per partition by the engine's cost model).\n\
+                           Special rows fall on multiples of the strip height; use 1024 or\n\
+                           2048 to share a special-rows area with CUDAlign (8192 spacing).\n\
 "
 
 #define ARG_GPU        0x1001
@@ -60,13 +64,48 @@ int Mi355AlignerParameters::fastestGPU() {
     return best;
 }
 
+// Weight of every usable GPU (compute units x clock in MHz), for MASA-Core's --fork split of seq1
+// (AbstractAligner::setForkCount; the reference: X/CUDAligner.cpp:63-66, X/cuda_util.cpp:191-257).  The aligner
+// object is constructed BEFORE MASA-Core forks its per-GPU children, and a HIP runtime initialised in the parent
+// cannot be used in a child: the devices are therefore enumerated in a throw-away child process that reports
+// through a pipe and exits with its runtime.
+int Mi355AlignerParameters::deviceWeights(int* weights, int max) {
+    int fd[2];
+    if (pipe(fd) != 0) return 0;
+    const pid_t pid = fork();
+    if (pid < 0) { close(fd[0]); close(fd[1]); return 0; }
+    if (pid == 0) {
+        close(fd[0]);
+        const int n = mi355sw_device_count();
+        for (int d = 0; d < n; d++) {
+            char name[8]; int32_t cus = 0, mhz = 0; int64_t bytes = 0;
+            int w = 0;
+            if (mi355sw_device_info(d, name, sizeof(name), &cus, &mhz, &bytes) == MI355SW_OK) w = cus * (mhz > 0 ? mhz : 1);
+            if (write(fd[1], &w, sizeof(w)) != (ssize_t) sizeof(w)) _exit(1);
+        }
+        close(fd[1]);
+        _exit(0);
+    }
+    close(fd[1]);
+    int count = 0, w = 0;
+    while (read(fd[0], &w, sizeof(w)) == (ssize_t) sizeof(w))
+        if (count < max) weights[count++] = w;
+    close(fd[0]);
+    int status = 0;
+    waitpid(pid, &status, 0);
+    return count;
+}
+
 int Mi355AlignerParameters::processArgument(int argc, char** argv) {
     const int ret = AbstractAlignerParameters::callGetOpt(argc, argv, long_options);
     switch (ret) {
     case ARG_GPU:
-        if (optarg != NULL) sscanf(optarg, "%d", &gpu);
-        if (gpu < 0 || gpu >= mi355sw_device_count()) {
-            setLastError("GPU index out of range (see --list-gpus).");
+        // Only parsed here.  The range is checked in Mi355Aligner::initialize(), i.e. after MASA-Core has forked its
+        // --fork / --split children (libmasa.cpp:1204, :581): asking the HIP runtime for the device count here
+        // would initialise it in the parent, and a runtime inherited across fork() is unusable in the children
+        // (the reference only runs sscanf at this point too, X/CUDAlignerParameters.cpp:84-88).
+        if (optarg == NULL || sscanf(optarg, "%d", &gpu) != 1 || gpu < 0) {
+            setLastError("--gpu needs a non-negative device index (see --list-gpus).");
             return -1;
         }
         break;

@@ -23,6 +23,7 @@ public:
     int getStripRows() const { return stripRows; }    /* --strip-rows: 256..2048, 0 = cost model */
     static void printGPUDevices(FILE* file);          /* --list-gpus (X/cuda_util.cpp:191-230) */
     static int fastestGPU();                          /* X/cuda_util.cpp:238-287: largest CUs x clock */
+    static int deviceWeights(int* weights, int max);  /* X/cuda_util.cpp:191-257: per-GPU weights, asked from a child process */
 
 private:
     int gpu, waves, stripRows;

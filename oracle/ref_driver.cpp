@@ -30,6 +30,8 @@
 #include <string.h>
 #include <string>
 #include <vector>
+#include <sys/wait.h>
+#include <unistd.h>
 #include <algorithm>
 
 #include "libmasa/libmasa.hpp"
@@ -244,6 +246,8 @@ int main(int argc, char** argv) {
     int split_count = 0, split_step = 0;
     int max_alignments = 1;
     std::string flush_url, load_url;
+    bool do_fork = false;
+    std::vector<int> fork_weights;
     std::vector<const char*> files;
     std::vector<char*> extension_args;
 
@@ -262,6 +266,11 @@ int main(int argc, char** argv) {
         else if (!strncmp(s, "--flush-column=", 15)) { flush_url = s + 15; pruning = false; }
         else if (!strncmp(s, "--load-column=", 14)) { load_url = s + 14; pruning = false; }
         else if (!strncmp(s, "--max-alignments=", 17)) max_alignments = atoi(s + 17);
+        else if (!strcmp(s, "--fork")) do_fork = true;                       /* weights from IAligner::getForkWeights */
+        else if (!strncmp(s, "--fork=", 7)) {                                /* --fork=W1,W2,... (libmasa.cpp:964-980) */
+            do_fork = true;
+            for (const char* q = s + 7; *q; ) { fork_weights.push_back(atoi(q)); q = strchr(q, ','); if (!q) break; q++; }
+        }
         else if (s[0] == '-') extension_args.push_back(argv[a]);    /* libmasa.cpp hands unknown options to the extension */
         else files.push_back(s);
     }
@@ -340,6 +349,51 @@ int main(int argc, char** argv) {
         }
         ap->getSequence(1)->trim(trim_j0, trim_j1);
         job->block_pruning = false;
+    }
+
+    /* libmasa.cpp:1305-1325 + fork_multi_process (:540-642): one child per positive weight, chained through
+     * socket://127.0.0.1:7000+id, seq1 trimmed in proportion to the weights, work dir FORK.NN (Job.cpp:127) */
+    if (do_fork) {
+        if (fork_weights.empty()) {
+            const int* w = aligner->getForkWeights();
+            for (int k = 0; w && w[k] != 0; k++) fork_weights.push_back(w[k]);
+        }
+        const int count = (int) fork_weights.size();
+        if (count == 0) { fprintf(stderr, "No forked instances allowed.\n"); return 1; }
+        job->block_pruning = false;
+        std::vector<long long> prop(count + 1, 0);
+        std::vector<int> prev(count + 1, -1);
+        int firstId = -1, lastId = -1;
+        for (int i = 0; i < count; i++) {
+            prop[i + 1] = prop[i] + fork_weights[i];
+            if (fork_weights[i] > 0) { if (firstId < 0) firstId = i; prev[i] = lastId; lastId = i; }
+        }
+        for (int i = 0; i < count; i++)
+            printf("fork[%d%c]: %.2f%%\n", i, (i >= firstId && i <= lastId) ? '+' : ' ', (prop[i + 1] - prop[i]) * 100.0 / prop[count]);
+        if (firstId < 0) { fprintf(stderr, "No forked instances with valid weight.\n"); return 1; }
+        fflush(stdout);
+        bool parent = true;
+        int me = -1;
+        for (int i = 0; i < count && parent; i++) {
+            if (fork_weights[i] <= 0) continue;
+            const pid_t pid = fork();
+            if (pid == 0) {
+                parent = false; me = i;
+                aligner->getParameters()->setForkId(i);
+                char str[128];
+                if (i > firstId) { sprintf(str, "socket://127.0.0.1:%d", 7000 + prev[i]); job->load_column_url = str; }
+                if (i < lastId) { sprintf(str, "socket://127.0.0.1:%d", 7000 + i); job->flush_column_url = str; }
+            }
+        }
+        if (parent) {
+            int status = 0, bad = 0;
+            while (wait(&status) > 0) if (!WIFEXITED(status) || WEXITSTATUS(status) != 0) bad = 1;
+            return bad;
+        }
+        const int seq1_len = ap->getSequence(1)->getLen();
+        const int trim_j0 = (int) (((long long) seq1_len * prop[me]) / prop[count] + 1);
+        const int trim_j1 = (int) (((long long) seq1_len * prop[me + 1]) / prop[count]);
+        ap->getSequence(1)->trim(trim_j0, trim_j1);
     }
 
     if (!job->initialize()) { fprintf(stderr, "job init failed\n"); return 1; }

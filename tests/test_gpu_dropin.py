@@ -92,9 +92,79 @@ def test_extension_command_line_options(pkg, oracle):
     p = subprocess.run([BIN, "--list-gpus", "a", "b"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=120)
     out = p.stdout.decode(errors="replace")
     assert p.returncode == 1 and "Available GPUs:" in out and "[fastest]" in out, out
-    p = subprocess.run([BIN, "--gpu=99", "a", "b"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=120)
-    assert p.returncode == 2 and b"out of range" in p.stdout
+    p = subprocess.run([BIN, "--gpu=-1", "a", "b"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=120)
+    assert p.returncode == 2 and b"non-negative" in p.stdout
     case = [c for c in G["cases"] if c["name"] == "sw_unrelated_ties_20000x17000"][0]
     args = [a for a in case["args"] if not a.startswith("--block=")]
     res = _run(pkg, oracle, case["seq"], args + ["--gpu=0", "--blocks=64", "--strip-rows=512"])
     assert list(res["best"]) == case["best"]
+    # the index range is checked when the engine starts (after any fork), not while the options are parsed
+    s0, s1 = make_pair(pkg, case["seq"])
+    tmp = tempfile.mkdtemp(prefix="masa_gpu99_")
+    try:
+        from oracle.binding import _write_fasta
+        f0, f1 = os.path.join(tmp, "s0.fasta"), os.path.join(tmp, "s1.fasta")
+        _write_fasta(f0, s0, "s0")
+        _write_fasta(f1, s1, "s1")
+        p = subprocess.run([BIN, "--work-dir=" + os.path.join(tmp, "work"), "--gpu=99"] + args + [f0, f1], stdout=subprocess.PIPE,
+                           stderr=subprocess.STDOUT, timeout=120, cwd=tmp)
+        assert p.returncode == 2 and b"out of range" in p.stdout
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def test_full_pipeline_with_block_pruning_biting(pkg, oracle):
+    """stages 1-6 on a fixture the reference produced with block pruning ON and biting (143 of its 392 blocks pruned).
+    The engine prunes too -- with its own granularity, so its special rows differ from the reference's off the optimal
+    path -- and MASA-Core's stages 2-6 on top of it must still recover the same crosspoints and print the same
+    alignment, byte for byte."""
+    case = [c for c in G["cases"] if c["name"] == "full_pipeline_pruned_60000x50000_b8192"][0]
+    assert case["pruned_blocks"][0] > 0
+    out = _run(pkg, oracle, case["seq"], ["--disk-size=4M", "--strip-rows=1024"])
+    assert list(out["best"]) == case["best"]
+    stats = out["statistics"]["statistics_01.00"]
+    pruned = [int(ln.split(":")[1]) for ln in stats.splitlines() if ln.startswith("Pruned cells:")]
+    assert pruned and pruned[0] > 0.15 * case["m"] * case["n"], stats[-600:]
+    assert out.get("crosspoints_2") == [tuple(x) for x in case["crosspoints_2"]]
+    assert hashlib.sha256(out["alignment_txt"]).hexdigest() == case["alignment_txt_sha256"]
+    # the special rows MASA-Core stored: same rows as the reference's, each a lower bound with the same maximum
+    got = {i: a for (d, i), a in out["special_rows"].items()}
+    assert sorted(got) == sorted(int(k) for k in case["special_rows"] if int(k) < case["m"])
+
+
+def _run_forked(pkg, seq, args):
+    from oracle.binding import _write_fasta, read_ref_work
+    s0, s1 = make_pair(pkg, seq)
+    tmp = tempfile.mkdtemp(prefix="masa_fork_")
+    try:
+        f0, f1 = os.path.join(tmp, "s0.fasta"), os.path.join(tmp, "s1.fasta")
+        _write_fasta(f0, s0, "s0")
+        _write_fasta(f1, s1, "s1")
+        work = os.path.join(tmp, "work")
+        p = subprocess.run([BIN, "--work-dir=" + work] + args + [f0, f1], stdout=subprocess.PIPE,
+                           stderr=subprocess.STDOUT, timeout=600, cwd=tmp)
+        log = p.stdout.decode(errors="replace")
+        assert p.returncode == 0, log[-3000:]
+        forks = sorted(d for d in os.listdir(work) if d.startswith("FORK."))
+        return log, [read_ref_work(os.path.join(work, d)) for d in forks]
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def test_fork_chain_through_masa_core(pkg, oracle):
+    """MASA-Core's own multi-GPU mode (--fork: one process per GPU, seq1 split by the aligner's fork weights, boundary
+    columns through its socket chain, best score relayed through AlignerPool) with the product adapter in every
+    process.  The box has one GPU, so explicit weights give three processes whose fork ids wrap onto it; the running
+    bests of the three bands are the reference chain's."""
+    if not os.path.exists(BIN):
+        pytest.skip("oracle/_ref/masa_mi355 not prebuilt (needs /root/reference at build time)")
+    ch = G["chain"]
+    log, forks = _run_forked(pkg, ch["seq"], ["--stage-1", "--no-flush", "--fork=1,1,1"])
+    assert len(forks) == 3
+    assert [list(f["best"]) for f in forks] == ch["band_bests"]
+    assert "Wrapping gpu ID" in log
+    # --fork without weights: one instance per GPU, weighted by compute units x clock.  The weights are asked from
+    # a throw-away child process (a HIP runtime initialised before MASA-Core forks would be unusable afterwards).
+    log, forks = _run_forked(pkg, ch["seq"], ["--stage-1", "--no-flush", "--fork"])
+    assert "fork[0+]: 100.00%" in log and len(forks) == 1
+    assert list(forks[0]["best"]) == ch["single_best"]
