@@ -61,8 +61,9 @@ struct mi355sw_handle {
     bool have_seq = false;
     int len0 = 0, len1 = 0;
     DevBuf d_seq0, d_seq1;
-    bool profile = false;
-    int n_match_codes = 0, pad_code = 0;
+    bool profile = false;           // coded sequences with <= 7 codes: the int32 nibble-profile kernel applies
+    bool packed_ok = false;         // coded sequences with <= 14 codes: the packed 16-bit kernel applies
+    int n_match_codes = 0, pad_code = 0, seq0_shift = 0;
 
     // work buffers
     DevBuf d_bus, d_first_col, d_special, d_last_row, d_progress, d_strip_best, d_ctrl, d_kargs, d_trace, d_ckpt, d_seed;
@@ -252,26 +253,39 @@ int mi355sw_set_sequences(mi355sw_handle* h, const char* seq0, const char* seq1,
     HIPCHK(h, hipSetDevice(h->device));
     const unsigned char* s0 = (const unsigned char*) seq0;
     const unsigned char* s1 = (const unsigned char*) seq1;
-    bool in0[256] = {false}, in1[256] = {false};
-    for (int k = 0; k < len0; k++) in0[s0[k]] = true;
-    for (int k = 0; k < len1; k++) in1[s1[k]] = true;
+    // byte histogram of both sequences: bytes present in BOTH can match each other (raw byte equality,
+    // X/CUDAligner.cu:276-289), every other byte never matches anything
+    long long cnt0[256] = {0}, cnt1[256] = {0};
+    for (int k = 0; k < len0; k++) cnt0[s0[k]]++;
+    for (int k = 0; k < len1; k++) cnt1[s1[k]]++;
     int common = 0;
-    for (int b = 0; b < 256; b++) common += (in0[b] && in1[b]);
-    h->profile = (common <= 7) && !(h->cfg.flags & MI355SW_F_FORCE_GENERIC_COMPARE);
+    for (int b = 0; b < 256; b++) common += (cnt0[b] > 0 && cnt1[b] > 0);
+    // Coded form ("profile"): common bytes become codes 0..K-1, most frequent first -- the packed kernel scores a
+    // chunk with one byte permute when every column in reach carries a code < 4, so the four commonest letters
+    // (A, C, G, T of a genome, whatever else it contains) must be the ones below 4.
+    //   K <= 14: packed 16-bit kernel (one-hot bit 2+code in a 16-bit half)
+    //   K <=  7: int32 nibble-profile kernel as its overflow fallback; 8..14: int32 byte-compare kernel on the codes
+    h->packed_ok = (common <= 14) && !(h->cfg.flags & MI355SW_F_FORCE_GENERIC_COMPARE);
+    h->profile = h->packed_ok && common <= 7;
     std::vector<unsigned char> c0((size_t) len0 + 64), c1((size_t) len1 + 64);
-    if (h->profile) {
-        // bytes present in both sequences get codes 0..K-1; every other byte can never match:
-        // code 7 in either sequence (profile nibble 7 is always "mismatch")
-        unsigned char lut[256];
-        int k = 0;
-        for (int b = 0; b < 256; b++) lut[b] = (in0[b] && in1[b]) ? (unsigned char) k++ : (unsigned char) 7;
+    if (h->packed_ok) {
+        int order[256], k = 0;
+        for (int b = 0; b < 256; b++) if (cnt0[b] > 0 && cnt1[b] > 0) order[k++] = b;
+        std::stable_sort(order, order + k, [&](int x, int y) { return cnt0[x] + cnt1[x] > cnt0[y] + cnt1[y]; });
+        // bytes of one sequence only: a code no byte of the other sequence can carry
+        const int foreign0 = (k <= 7) ? 7 : 14, foreign1 = (k <= 7) ? 7 : 15;
+        unsigned char lut0[256], lut1[256];
+        for (int b = 0; b < 256; b++) { lut0[b] = (unsigned char) foreign0; lut1[b] = (unsigned char) foreign1; }
+        for (int q = 0; q < k; q++) { lut0[order[q]] = (unsigned char) q; lut1[order[q]] = (unsigned char) q; }
         h->n_match_codes = k;
-        h->pad_code = 7;
-        for (int i = 0; i < len0; i++) c0[i] = lut[s0[i]];
-        for (int j = 0; j < len1; j++) c1[j] = (unsigned char) (lut[s1[j]] * 4);   // v_bfe_i32 bit offset
+        h->pad_code = foreign0;
+        h->seq0_shift = 2;
+        for (int i = 0; i < len0; i++) c0[i] = lut0[s0[i]];
+        for (int j = 0; j < len1; j++) c1[j] = (unsigned char) (lut1[s1[j]] * 4);   // v_bfe_i32 bit offset / code << 2
     } else {
         h->n_match_codes = 256;
         h->pad_code = 256;     // rows beyond m never equal any byte
+        h->seq0_shift = 0;
         memcpy(c0.data(), s0, (size_t) len0);
         memcpy(c1.data(), s1, (size_t) len1);
     }
@@ -354,7 +368,7 @@ int mi355sw_stream_begin(mi355sw_handle* h, const mi355sw_partition* part, const
     const int m = part->i1 - part->i0, n = part->j1 - part->j0;
     h->m = m; h->n = n;
     {
-        const bool will16 = h->profile && !p->force_int32 &&
+        const bool will16 = h->packed_ok && !p->force_int32 &&
                             !(h->cfg.flags & MI355SW_F_FORCE_INT32);
         h->R = pick_rows_per_lane(h, m, n, will16);
         // the int32 kernels are instantiated for R in {4,8,16}
@@ -380,7 +394,7 @@ int mi355sw_stream_begin(mi355sw_handle* h, const mi355sw_partition* part, const
         h->n_special = (int) (((long long) m - 1) / ((long long) K * h->SH));   // rows K*SH*k < m
     }
     h->special_pitch = ((long long) n + 63) / 64 * 64;
-    h->use16 = h->profile && !p->force_int32 &&
+    h->use16 = h->packed_ok && !p->force_int32 &&
                !(h->cfg.flags & MI355SW_F_FORCE_INT32);
     // Two-phase best: the main pass keeps only each strip's best VALUE (no per-step position test, no
     // rare path on the start-up critical path of every strip); the canonical cell is then recomputed
@@ -512,6 +526,7 @@ int mi355sw_stream_begin(mi355sw_handle* h, const mi355sw_partition* part, const
     a.m = m; a.n = n;
     a.n_match_codes = h->n_match_codes;
     a.pad_code = h->pad_code;
+    a.seq0_shift = h->seq0_shift;
     a.num_strips = h->strips;
     a.strip_row0 = 0;
     a.strip_index0 = 0;

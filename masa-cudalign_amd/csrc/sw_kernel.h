@@ -18,6 +18,8 @@ struct KernelArgs {
     int m, n;
     int n_match_codes;           // PROFILE: codes < this can match; others never do
     int pad_code;                // code used for rows >= m
+    int seq0_shift;              // byte-compare kernels: seq0 bytes are compared as (byte << seq0_shift) with seq1 bytes
+                                 // (coded sequences keep seq1 as code*4; raw sequences: 0)
     // strip geometry
     int num_strips;              // strips in this launch
     int strip_row0;              // DP row of strip 0 of this launch

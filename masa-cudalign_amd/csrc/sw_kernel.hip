@@ -224,7 +224,7 @@ __device__ __attribute__((noinline)) void process_strip(const KernelArgs* ap, co
             if (c0 < a->n_match_codes) p += (4u << (4 * c0));
             st.prof[r] = (int) p;
         } else {
-            st.prof[r] = c0;
+            st.prof[r] = c0 << a->seq0_shift;
         }
     }
     {

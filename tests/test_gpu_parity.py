@@ -580,3 +580,38 @@ def test_match_last_column_follows_aligner_utils(pkg, oracle, aligner):
     with_inf = np.array([[5, -pkg.INF], [7, 3]], dtype=np.int32)
     got = aligner.matchLastColumn(with_inf, np.array([[1, -pkg.INF], [2, 4]], dtype=np.int32), 10)
     assert got == {"found": True, "k": 1, "score": 4, "type": 1}
+
+
+@pytest.mark.parametrize("letters", [b"ACGTNRYKM", b"ACGTNRYKMSWBDH", b"ACGTNRYKMSWBDHV"])
+def test_iupac_alphabets_stay_on_the_packed_kernel(pkg, oracle, letters):
+    """up to 14 byte values common to both sequences are coded (most frequent first) and run on the packed kernel;
+    its int32 stand-in for 8..14 letters is the byte-compare kernel on the codes; 15 and more fall back to raw byte
+    compare.  Letters of one sequence only never match.  All three agree with the oracle bit for bit."""
+    rng = np.random.default_rng(len(letters))
+    alpha = np.frombuffer(letters, dtype=np.uint8)
+    # genome-like: mostly ACGT, IUPAC codes sprinkled in, runs of N
+    m, n = 7000, 9000
+    s0 = alpha[rng.integers(0, 4, m)].copy()
+    s1 = s0[:min(m, n)].copy()
+    s1 = np.concatenate([s1, alpha[rng.integers(0, 4, n - len(s1))]])
+    for s in (s0, s1):
+        idx = rng.integers(0, len(s), len(s) // 40)
+        s[idx] = alpha[rng.integers(0, len(alpha), len(idx))]
+        s[len(s) // 2: len(s) // 2 + 90] = ord("N")
+    s0[5::211] = ord("@")            # bytes of one sequence only
+    s1[7::199] = ord("#")
+    ref = oracle.stage1(s0, s1, want_last_row=True, want_last_col=True)
+    want_kernel = 2 if len(letters) <= 14 else 0
+    for flags in (0, 2):
+        al = pkg.MI355Aligner(device=0, flags=flags)
+        try:
+            al.setSequences(s0, s1)
+            part = pkg.Partition(0, 0, m, n)
+            mg = pkg.Stage1Manager(part, keep_last_row=True, keep_last_column=True)
+            al.alignPartition(part, mg)
+            assert al.getStatistics()["profile_kernel"] == (want_kernel if flags == 0 else 0)
+            assert tuple(mg.getBestScore()) == tuple(ref["best"])
+            assert np.array_equal(mg.lastRow(), ref["last_row"])
+            assert np.array_equal(mg.lastColumn(), ref["last_col"])
+        finally:
+            al.close()
