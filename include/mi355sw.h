@@ -104,6 +104,12 @@ typedef struct {
     int32_t (*must_dispatch_special_rows)(void* user);
     int32_t (*must_dispatch_scores)(void* user);
     int32_t (*must_prune_blocks)(void* user);
+    /* OPTIONAL (may be NULL; MASA-Core's IManager has no such call).  Partitions of >= 32 Mi rows track only the
+     * best VALUE per strip in the main pass and locate the winning cell afterwards; a caller that checkpoints
+     * (special rows on disk + resume) is told here, before every special row, the best value of the strips above it:
+     * rows [row_lo, row_hi) hold a cell of that score.  Exact (i, j, score) records, where the engine has them, go
+     * through dispatch_score at the same points. */
+    void (*dispatch_strip_value)(void* user, int32_t row_lo, int32_t row_hi, int32_t score);
 } mi355sw_manager;
 
 /* Timing / accounting of the last mi355sw_align_partition (reference: Timer events + MCUPS line,

@@ -15,3 +15,5 @@ from .manager import (  # noqa: F401
     AT_NOWHERE, AT_ANYWHERE, AT_SEQUENCE_1, AT_SEQUENCE_2, AT_SEQUENCE_1_OR_2, AT_SEQUENCE_1_AND_2,
 )
 from . import seqgen  # noqa: F401
+from . import sra  # noqa: F401
+from .stage1 import stage1  # noqa: F401

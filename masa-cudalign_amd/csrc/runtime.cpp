@@ -1000,6 +1000,32 @@ int mi355sw_stream_strip_scores(mi355sw_handle* h, mi355sw_score* out, int32_t m
     return cnt;
 }
 
+// Best-score records of the strips [*rows_sent / SH, upto_strip) of the ACTIVE stream, handed to the manager while
+// the kernel is still running (AbstractDiagonalAligner::flushBlockScores, :392-403, does it once per diagonal): a
+// caller that checkpoints needs the best of everything above a special row at the moment it stores that row.
+static int flush_strip_scores(mi355sw_handle* h, const mi355sw_partition* part, const mi355sw_manager* mg, void* user,
+                              int upto_strip, int* rows_sent) {
+    const int first = *rows_sent / h->SH;
+    if (upto_strip > h->strips) upto_strip = h->strips;
+    if (upto_strip <= first) return MI355SW_OK;
+    std::vector<int4> rec((size_t) (upto_strip - first));
+    HIPCHK(h, hipMemcpyAsync(rec.data(), (int4*) h->d_strip_best.p + first, sizeof(int4) * rec.size(), hipMemcpyDeviceToHost, h->copy));
+    HIPCHK(h, hipStreamSynchronize(h->copy));
+    for (int s = first; s < upto_strip; s++) {
+        const int4 r = rec[(size_t) (s - first)];
+        if (r.w == 1 && r.z >= 0) {
+            mi355sw_score sc;
+            sc.score = r.x; sc.i = r.y + part->i0; sc.j = r.z + part->j0;
+            mg->dispatch_score(user, sc, -1, -1);
+        } else if (r.w == 2 && r.x > -MI355SW_INF && mg->dispatch_strip_value) {
+            const long long lo = (long long) s * h->SH, hi = std::min<long long>(lo + h->SH, h->m);
+            mg->dispatch_strip_value(user, part->i0 + (int) lo, part->i0 + (int) hi, r.x);
+        }
+    }
+    *rows_sent = (int) std::min<long long>((long long) upto_strip * h->SH, h->m);
+    return MI355SW_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // IAligner::alignPartition on top of the streaming form
 // ------------------------------------------------------------------------------------------------
@@ -1076,6 +1102,7 @@ int mi355sw_align_partition(mi355sw_handle* h, const mi355sw_partition* part, co
     //  replay state is kept in DP rows, not in strips)
     int fed = 0, col_sent = 0;
     int special_last_row = 0;             // DP row of the last special row handed over
+    int scores_rows_sent = 0;             // rows whose strip records have been handed over
     bool stopped = false;
     int stop_rows = 0;                    // rows that were complete (and dispatched) when the manager said stop
     std::vector<mi355sw_cell> rowbuf;
@@ -1118,6 +1145,8 @@ int mi355sw_align_partition(mi355sw_handle* h, const mi355sw_partition* part, co
             const int dp_row = (special_sent + 1) * h->special_interval_strips * SH;
             if (dp_row > (stopped ? stop_rows : rows_done)) break;
             if (dp_row <= special_last_row) { special_sent++; continue; }   // handed over by the attempt before
+            // the scores of everything above the row first: whoever stores the row as a checkpoint stores them with it
+            if (want_scores && (rc = flush_strip_scores(h, part, mg, user, dp_row / SH, &scores_rows_sent))) { mi355sw_stream_abort(h); mi355sw_stream_end(h, nullptr, nullptr); return rc; }
             mi355sw_cell c;
             if (orig_col_type == MI355SW_INIT_WITH_ZEROES) { c.h = 0; }
             else c = ((const mi355sw_cell*) h->p_first_col.p)[dp_row];      // cell of DP row dp_row (index 0 = corner)
@@ -1177,10 +1206,20 @@ int mi355sw_align_partition(mi355sw_handle* h, const mi355sw_partition* part, co
         for (int j = 0; j < n; j += CH) mg->dispatch_row(user, part->i1, lastrow.data() + j, std::min(CH, n - j));
     }
     if (want_scores) {
-        // AbstractDiagonalAligner::flushBlockScores (:392-403): one score per strip instead of per block
-        std::vector<mi355sw_score> sc((size_t) h->strips);
-        const int cnt = mi355sw_stream_strip_scores(h, sc.data(), h->strips);
-        for (int k = 0; k < cnt; k++) mg->dispatch_score(user, sc[(size_t) k], -1, -1);
+        // AbstractDiagonalAligner::flushBlockScores (:392-403): one score per strip instead of per block.  What was
+        // not handed over next to a special row follows now; the two-phase scheme only knows its one exact cell.
+        if (h->two_phase) {
+            if (best.j >= 0) mg->dispatch_score(user, best, -1, -1);
+        } else {
+            const int first = scores_rows_sent / h->SH;
+            for (int sidx = first; sidx < h->strips; sidx++) {
+                const int4 r = h->strip_best_host[(size_t) sidx];
+                if (r.w == 0 || r.z < 0) continue;
+                mi355sw_score sc;
+                sc.score = r.x; sc.i = r.y + part->i0; sc.j = r.z + part->j0;
+                mg->dispatch_score(user, sc, -1, -1);
+            }
+        }
     }
     if (want_last_cell) {
         mi355sw_score s;

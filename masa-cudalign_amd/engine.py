@@ -112,6 +112,7 @@ CB_PART = C.CFUNCTYPE(None, _VP, C.POINTER(Partition))
 CB_RECV = C.CFUNCTYPE(None, _VP, C.POINTER(Cell), C.c_int32)
 CB_DISP = C.CFUNCTYPE(None, _VP, C.c_int32, C.POINTER(Cell), C.c_int32)
 CB_SCORE = C.CFUNCTYPE(None, _VP, Score, C.c_int32, C.c_int32)
+CB_VALUE = C.CFUNCTYPE(None, _VP, C.c_int32, C.c_int32, C.c_int32)
 
 
 class ManagerTable(C.Structure):
@@ -123,7 +124,7 @@ class ManagerTable(C.Structure):
                 ("must_continue", CB_INT), ("must_dispatch_last_cell", CB_INT),
                 ("must_dispatch_last_row", CB_INT), ("must_dispatch_last_column", CB_INT),
                 ("must_dispatch_special_rows", CB_INT), ("must_dispatch_scores", CB_INT),
-                ("must_prune_blocks", CB_INT)]
+                ("must_prune_blocks", CB_INT), ("dispatch_strip_value", CB_VALUE)]
 
 
 # every symbol include/mi355sw.h declares (tests check the .so exports all of them)
@@ -466,5 +467,7 @@ def make_manager_table(mgr):
         must_dispatch_scores=CB_INT(guard(lambda u: int(mgr.mustDispatchScores()))),
         must_prune_blocks=CB_INT(guard(lambda u: int(mgr.mustPruneBlocks()))),
     )
+    if hasattr(mgr, "dispatchStripValue"):      # optional: best VALUE per strip of a two-phase run (see mi355sw.h)
+        keep["dispatch_strip_value"] = CB_VALUE(guard(lambda u, lo, hi, sc: mgr.dispatchStripValue(lo, hi, sc), None))
     table = ManagerTable(**keep)
     return table, keep

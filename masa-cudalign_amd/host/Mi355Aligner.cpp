@@ -130,6 +130,7 @@ void Mi355Aligner::alignPartition(Partition partition) {
     m.must_dispatch_special_rows = cbSpecialRows;
     m.must_dispatch_scores = cbScores;
     m.must_prune_blocks = cbPrune;
+    m.dispatch_strip_value = NULL;      /* IManager has no value-only score call */
     mi355sw_partition p;
     p.i0 = partition.getI0(); p.j0 = partition.getJ0(); p.i1 = partition.getI1(); p.j1 = partition.getJ1();
     check(mi355sw_align_partition(handle, &p, &m, this), "mi355sw_align_partition");

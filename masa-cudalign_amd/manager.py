@@ -32,6 +32,9 @@ class InitialCellsReader:
         return self.type
 
     def read(self, buf, length):
+        if buf is None:                 # skip `length` cells (SpecialRowsPartition::continueFromLastRow reads into NULL)
+            self.position += length
+            return length
         if self.type == INIT_WITH_ZEROES:
             buf[:length, 0] = 0
             buf[:length, 1] = -INF
@@ -56,7 +59,8 @@ class ArrayCellsReader:
         return INIT_WITH_CUSTOM_DATA
 
     def read(self, buf, length):
-        buf[:length] = self.cells[self.position:self.position + length]
+        if buf is not None:
+            buf[:length] = self.cells[self.position:self.position + length]
         self.position += length
         return length
 
@@ -101,7 +105,7 @@ class Stage1Manager:
     def __init__(self, partition, alignment_start=AT_ANYWHERE, alignment_end=AT_ANYWHERE,
                  special_row_interval=0, keep_last_row=False, keep_last_column=False,
                  first_row_reader=None, first_column_reader=None, seq0_offset=0, seq1_offset=0,
-                 super_partition=None, block_pruning=False):
+                 super_partition=None, block_pruning=False, sra_partition=None, status=None):
         self.partition = partition
         self.super_partition = super_partition or partition
         self.seq0_offset, self.seq1_offset = seq0_offset, seq1_offset
@@ -127,6 +131,10 @@ class Stage1Manager:
         self.keep_last_row, self.keep_last_column = keep_last_row, keep_last_column
         # sw_stage1.cpp:219-225: pruning only when the alignment may end anywhere
         self.block_pruning = block_pruning and alignment_end == AT_ANYWHERE
+        # special rows / last row go to disk when a SpecialRowsPartition is given (AlignerManager::dispatchRow ->
+        # SpecialRowsPartition::write, AlignerManager.cpp:334-356); the status file follows every completed row
+        self.sra, self.status = sra_partition, status
+        self.value_best = None      # (score, row_lo, row_hi): best strip VALUE of a two-phase run (dispatchStripValue)
         self.active = True
         self.special_rows = {}      # dp row -> list of chunks
         self.last_row_chunks, self.last_column_chunks = [], []
@@ -170,7 +178,12 @@ class Stage1Manager:
 
     def dispatchRow(self, i, buf, length):
         i += self.seq0_offset
-        if self.mustDispatchSpecialRows():
+        if self.sra is not None:
+            if self.sra.write(i, buf[:length]) and self.status is not None:
+                self.status.last_special_row = i
+                self.status.merge_value_best(self.value_best)
+                self.status.save(self.best_list.best)
+        elif self.mustDispatchSpecialRows():
             self.special_rows.setdefault(i, []).append(np.array(buf[:length], copy=True))
         if i == self.partition.i1:
             if self.keep_last_row:
@@ -191,6 +204,15 @@ class Stage1Manager:
                 if i == self.partition.i1 and j == self.partition.j1:
                     self.best_list.add(i, j, s)
 
+    def dispatchStripValue(self, row_lo, row_hi, score):
+        """optional engine call (include/mi355sw.h): rows [row_lo, row_hi) hold a cell of `score`, position still
+        unknown (two-phase tracking).  Only the first strip reaching the maximum matters (canonical order: min i)."""
+        row_lo += self.seq0_offset
+        row_hi += self.seq0_offset
+        if self.best_location == AT_ANYWHERE and score >= self.best_list.min_score:
+            if self.value_best is None or score > self.value_best[0]:
+                self.value_best = (int(score), int(row_lo), int(row_hi))
+
     # --- must* (AlignerManager.cpp:455-503) ---
     def mustContinue(self):
         return self.active
@@ -199,7 +221,8 @@ class Stage1Manager:
         return self.best_location == AT_SEQUENCE_1_AND_2
 
     def mustDispatchLastRow(self):
-        return self.keep_last_row or self.best_location in (AT_SEQUENCE_1, AT_SEQUENCE_1_OR_2)
+        # a special-rows partition always takes the last row too (SpecialRowsPartition hands out a last-row writer)
+        return self.keep_last_row or self.sra is not None or self.best_location in (AT_SEQUENCE_1, AT_SEQUENCE_1_OR_2)
 
     def mustDispatchLastColumn(self):
         return self.keep_last_column or self.best_location in (AT_SEQUENCE_2, AT_SEQUENCE_1_OR_2)

@@ -1,0 +1,109 @@
+"""Native Stage-1 driver: what MASA-Core's stage1() does around the aligner (M/stage1/sw_stage1.cpp:203-240,
+:244-493), for the repo's own engine -- recurrence from the alignment edges, flush interval from the area limit
+(Job::calculateFlushIntervals), special rows + last row written to the Special Rows Area on disk in the
+reference's layout (sra.py), status file, crosspoint file, and RESUME: a run that was killed continues from the
+last complete special row (SpecialRowsPartition::continueFromLastRow) and ends with the same files and the same
+best score as an uninterrupted one."""
+import os
+import time
+
+from .engine import Partition
+from .manager import (Stage1Manager, ArrayCellsReader, InitialCellsReader, AT_ANYWHERE, AT_SEQUENCE_1, AT_SEQUENCE_2,
+                      AT_SEQUENCE_1_OR_2, GAP_OPEN, GAP_EXT)
+from . import sra as sra_mod
+
+
+def border_readers(alignment_start):
+    """getBorderCells, sw_stage1.cpp:137-161"""
+    if alignment_start in (AT_ANYWHERE, AT_SEQUENCE_1_OR_2):
+        return InitialCellsReader(), InitialCellsReader()
+    if alignment_start == AT_SEQUENCE_1:
+        return InitialCellsReader(), InitialCellsReader(GAP_OPEN, GAP_EXT)
+    if alignment_start == AT_SEQUENCE_2:
+        return InitialCellsReader(GAP_OPEN, GAP_EXT), InitialCellsReader()
+    return InitialCellsReader(GAP_OPEN, GAP_EXT), InitialCellsReader(GAP_OPEN, GAP_EXT)
+
+
+def stage1(aligner, seq0, seq1, work, alignment_start=AT_ANYWHERE, alignment_end=AT_ANYWHERE, sra_limit=0,
+           block_pruning=True, manager_class=Stage1Manager):
+    """Runs (or resumes) stage 1 of seq0 x seq1 in work directory `work`.  `aligner` is an MI355Aligner; create it
+    with a fixed strip height (rows_per_lane) when the area must be resumable or shared with CUDAlign: special rows
+    sit on multiples of the strip height (1024 or 2048 rows give CUDAlign's 8192-row spacing).
+    Returns {"best": (i, j, score) in 1-based DP coordinates, "resumed_from": row or None, "seconds", "gcups", ...}."""
+    m, n = len(seq0), len(seq1)
+    os.makedirs(work, exist_ok=True)
+    status = sra_mod.Status(work)
+    interval = sra_mod.flush_interval(m, n, sra_limit) if sra_limit > 0 else 0
+    fr, fc = border_readers(alignment_start)
+    i0, resumed_from, part_sra = 0, None, None
+    if sra_limit > 0:
+        part_sra = sra_mod.SpecialRowsPartition(sra_mod.special_rows_path(work, 1, 0), 0, 0, m, n)
+        last = part_sra.last_row_id()
+        if last == m and status.loaded:
+            # "Stage 1 was already executed" (sw_stage1.cpp:212-214)
+            return {"best": status.best, "resumed_from": m, "seconds": 0.0, "gcups": 0.0, "already_done": True,
+                    "special_rows": [r for r in part_sra.rows]}
+        if last != 0:
+            i0, row = part_sra.continue_from_last_row()
+            fc.read(None, i0)                      # firstColumnReader->read(NULL, lastRowId)
+            fr = ArrayCellsReader(row)             # FileCellsReader(lastRowFilename): cell 0 = the corner of the rest
+            resumed_from = i0
+        else:
+            part_sra.set_border_markers(fr.getType(), 0, fc.getType(), 0)
+    part = Partition(i0, 0, m, n)
+    mgr = manager_class(part, alignment_start=alignment_start, alignment_end=alignment_end,
+                        special_row_interval=interval, first_row_reader=fr, first_column_reader=fc,
+                        super_partition=Partition(0, 0, m, n), block_pruning=block_pruning,
+                        sra_partition=part_sra, status=status)
+    if status.loaded and status.best is not None and status.best[0] >= 0:
+        mgr.best_list.add(*status.best)            # Status::load -> bestScoreList->add (Status.cpp:60-64)
+    status.stage = 1
+    prefix_value = status.value_best            # left by the run(s) this one continues: strips above row i0
+    aligner.setSequences(seq0, seq1)
+    t0 = time.time()
+    try:
+        aligner.alignPartition(part, mgr)
+    finally:
+        if part_sra is not None:
+            part_sra.close()
+        aligner.unsetSequences()
+    dt = time.time() - t0
+    best = mgr.getBestScore()
+    # Two-phase tracking + resume: strips above the row this run continued from may only be known by VALUE (the run
+    # that computed them died before it could locate its best cell).  If that value beats -- or ties, the smaller row
+    # wins -- everything with a known position, its cell is located now: one exact pass from the special row above
+    # that strip down to the strip's last row, a 1/(number of special rows) slice of the matrix.
+    # (this run's own strips need none of that: the engine located their best cell itself before it returned)
+    located = None
+    vb = prefix_value
+    if vb is not None and part_sra is not None and (vb[0] > best[2] or (vb[0] == best[2] and vb[1] < best[0])):
+        above = [part_sra.i0 + r for r in part_sra.rows if part_sra.i0 + r <= vb[1]]
+        r0 = max(above) if above else 0
+        fr2, fc2 = border_readers(alignment_start)
+        if r0 > 0:
+            fc2.read(None, r0)
+            fr2 = ArrayCellsReader(part_sra.read_row(r0))
+        sub = Partition(r0, 0, min(vb[2], m), n)
+        mgr2 = manager_class(sub, alignment_start=alignment_start, alignment_end=alignment_end,
+                             first_row_reader=fr2, first_column_reader=fc2, super_partition=Partition(0, 0, m, n))
+        aligner.setSequences(seq0, seq1)
+        try:
+            aligner.alignPartition(sub, mgr2)
+        finally:
+            aligner.unsetSequences()
+        located = tuple(mgr2.getBestScore())
+        if located[2] != vb[0]:
+            raise RuntimeError("stage1 resume: rows [%d,%d) were recorded with best value %d, the exact pass finds %d"
+                               % (vb[1], vb[2], vb[0], located[2]))
+        mgr.best_list.add(*located)
+        best = mgr.getBestScore()
+    status.stage = 2
+    if part_sra is not None:
+        status.last_special_row = part_sra.last_row_id()
+    status.save(best)
+    sra_mod.write_crosspoint(sra_mod.crosspoint_path(work, 1, 0), best)
+    st = aligner.getStatistics()
+    return {"best": tuple(best), "resumed_from": resumed_from, "seconds": dt,
+            "gcups": float(m - i0) * n / dt / 1e9 if dt > 0 else 0.0, "strip_rows": st["strip_rows"],
+            "kernel_ms": st["kernel_ms"], "pruned_cells": st["pruned_cells"], "located_from_value": located,
+            "special_rows": list(part_sra.rows) if part_sra is not None else []}

@@ -203,15 +203,18 @@ def read_ref_work(work, log=""):
     out = {"log": log, "best": None, "special_rows": {}, "sra_dirs": []}
     cp = os.path.join(work, "crosspoints", "crosspoint_01.00")
     if os.path.exists(cp):
+        out["crosspoint_txt"] = open(cp).read()
         lines = open(cp).read().split()
         # START / type,i,j,score / END   (CrosspointsFile.cpp:99-150)
         t, i, j, s = [int(x) for x in lines[1].split(",")]
         out["best"] = (i, j, s)
     sra = os.path.join(work, "special_rows", "stage.01.00")
     if os.path.isdir(sra):
+        out["sra_listing"] = {}
         for d in sorted(os.listdir(sra)):
             full = os.path.join(sra, d)
             out["sra_dirs"].append(d)
+            out["sra_listing"][d] = {fn: os.path.getsize(os.path.join(full, fn)) for fn in sorted(os.listdir(full))}
             for fn in sorted(os.listdir(full)):
                 if len(fn) == 8 and all(c in "0123456789ABCDEF" for c in fn):
                     out["special_rows"][(d, int(fn, 16))] = \
@@ -226,6 +229,8 @@ def read_ref_work(work, log=""):
                 if ln.startswith("Pruned Blocks:") and fn == "statistics_01.00":
                     a, b = ln.split(":")[1].split("/")
                     out["pruned_blocks"] = [int(a), int(b)]
+    if os.path.exists(os.path.join(work, "status")):
+        out["status_txt"] = open(os.path.join(work, "status")).read()
     for fn in ("alignment.00.txt",):
         pth = os.path.join(work, fn)
         if os.path.exists(pth):

@@ -101,6 +101,9 @@ def main():
             assert rec["pruned_blocks"][0] > 0
         if case.get("special"):
             rec["special_rows"] = {str(i): cells_digest(a) for (d, i), a in sorted(ref["special_rows"].items())}
+            rec["sra_listing"] = ref["sra_listing"]          # directory and file names + sizes as MASA-Core wrote them
+            rec["status_txt"] = ref["status_txt"]
+            rec["crosspoint_txt"] = ref["crosspoint_txt"]
         if case.get("full"):
             rec["alignment_txt_sha256"] = hashlib.sha256(ref["alignment_txt"]).hexdigest()
             rec["crosspoints_2"] = ref.get("crosspoints_2")

@@ -1,0 +1,169 @@
+"""CPU: the native Special Rows Area writer / status file / stage-1 driver (masa-cudalign_amd/sra.py, stage1.py)
+against what MASA-Core itself wrote for the same pair (fixture: directory and file names, file sizes, sha256 of every
+row file, status and crosspoint text), and the resume logic: a run that is cut off in the middle -- leaving a
+half-written <row>.tmp behind -- continues from the last complete special row and ends with the same files and the
+same best score as an uninterrupted run.  The aligner here is a stand-in built on the oracle (the product engine
+needs a GPU; tests/test_gpu_sra.py repeats the same checks with it, including a SIGKILL)."""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+from helpers import load_golden, make_pair
+
+G = load_golden()
+CASE = [c for c in G["cases"] if c["name"] == "sw_special_rows_20000x9000"][0]
+
+
+class OracleAligner:
+    """IAligner surface used by stage1(): setSequences / alignPartition(partition, manager) / getStatistics, with the
+    oracle doing the arithmetic and the hook order of AbstractDiagonalAligner (special rows in increasing order with
+    their leading first-column cell, then the last row, then the scores)."""
+
+    def __init__(self, oracle, strip_rows=1024, chunk=4000):
+        self.o, self.strip_rows, self.chunk = oracle, strip_rows, chunk
+
+    def setSequences(self, s0, s1):
+        self.s0, self.s1 = np.asarray(s0), np.asarray(s1)
+
+    def unsetSequences(self):
+        pass
+
+    def getStatistics(self):
+        return {"strip_rows": self.strip_rows, "kernel_ms": 0.0, "pruned_cells": 0}
+
+    def alignPartition(self, part, mg):
+        """block rows of K rows (K = the special-row spacing), top to bottom: the scores of a block are dispatched
+        before the special row below it, as the engine does"""
+        o = self.o
+        m, n = part.i1 - part.i0, part.j1 - part.j0
+        row = np.zeros((n + 1, 2), dtype=np.int32)
+        col = np.zeros((m + 1, 2), dtype=np.int32)
+        mg.receiveFirstColumn(col[:1], 1)
+        mg.receiveFirstRow(row[:1], 1)
+        mg.receiveFirstRow(row[1:], n)
+        mg.receiveFirstColumn(col[1:], m)
+        interval = mg.getSpecialRowInterval()
+        K = m
+        if interval > 0 and mg.mustDispatchSpecialRows():
+            K = max(-(-interval // self.strip_rows), -(-8192 // self.strip_rows)) * self.strip_rows
+        r0 = 0
+        while r0 < m and mg.mustContinue():
+            r1 = min(r0 + K, m)
+            res = o.stage1(self.s0[part.i0 + r0:part.i0 + r1], self.s1[part.j0:part.j1], recurrence=mg.getRecurrenceType(),
+                           first_row_type=o.INIT_WITH_CUSTOM_DATA, custom_first_row=row,
+                           first_col_type=o.INIT_WITH_CUSTOM_DATA, custom_first_col=col[r0:r1 + 1],
+                           block_h=self.strip_rows, block_w=1 << 20, want_last_row=True)
+            row = res["last_row"]
+            if mg.mustDispatchScores() and res["best"][2] > -o.INF:
+                i, j, sc = res["best"]
+                mg.dispatchScore((part.i0 + r0 + i - 1, part.j0 + j - 1, sc))
+            if r1 < m or mg.mustDispatchLastRow():
+                lead = np.array([[col[r1, 0], -o.INF]], dtype=np.int32)
+                mg.dispatchRow(part.i0 + r1, lead, 1)
+                for j in range(0, n, self.chunk):
+                    mg.dispatchRow(part.i0 + r1, row[1 + j:1 + j + self.chunk], min(self.chunk, n - j))
+            r0 = r1
+
+
+def _sha(path):
+    return hashlib.sha256(open(path, "rb").read()).hexdigest()
+
+
+def _listing(work):
+    root = os.path.join(work, "special_rows", "stage.01.00")
+    return {d: {fn: os.path.getsize(os.path.join(root, d, fn)) for fn in sorted(os.listdir(os.path.join(root, d)))}
+            for d in sorted(os.listdir(root))}
+
+
+def _check_against_reference(work, res):
+    assert list(res["best"]) == CASE["best"]
+    assert _listing(work) == CASE["sra_listing"]                      # names and sizes as MASA-Core wrote them
+    d = list(CASE["sra_listing"])[0]
+    for rid, dg in CASE["special_rows"].items():
+        assert _sha(os.path.join(work, "special_rows", "stage.01.00", d, "%08X" % int(rid))) == dg["sha256"], rid
+    assert open(os.path.join(work, "status")).read() == CASE["status_txt"]
+    assert open(os.path.join(work, "crosspoints", "crosspoint_01.00")).read() == CASE["crosspoint_txt"]
+
+
+def test_area_written_like_masa_core(pkg, oracle, tmp_path):
+    s0, s1 = make_pair(pkg, CASE["seq"])
+    work = str(tmp_path / "work")
+    res = pkg.stage1(OracleAligner(oracle, strip_rows=1024), s0, s1, work, sra_limit=200 * 1024, block_pruning=False)
+    assert res["resumed_from"] is None
+    _check_against_reference(work, res)
+    # running it again finds stage 1 done (sw_stage1.cpp:212-214)
+    again = pkg.stage1(OracleAligner(oracle), s0, s1, work, sra_limit=200 * 1024)
+    assert again.get("already_done") and list(again["best"]) == CASE["best"]
+
+
+@pytest.mark.parametrize("stop_after_rows", [1, 2])
+def test_cut_off_run_resumes_to_the_same_result(pkg, oracle, tmp_path, stop_after_rows):
+    s0, s1 = make_pair(pkg, CASE["seq"])
+    work = str(tmp_path / "work")
+
+    class Killed(Exception):
+        pass
+
+    class DyingManager(pkg.Stage1Manager):
+        """dies in the middle of the row after `stop_after_rows` complete ones"""
+        calls = 0
+
+        def dispatchRow(self, i, buf, length):
+            pkg.Stage1Manager.dispatchRow(self, i, buf, length)
+            if len(self.sra.rows) >= stop_after_rows and length > 1:
+                DyingManager.calls += 1
+                if DyingManager.calls == 2:             # second chunk of the next row: a .tmp is on disk
+                    raise Killed()
+
+    with pytest.raises(Killed):
+        pkg.stage1(OracleAligner(oracle), s0, s1, work, sra_limit=200 * 1024, block_pruning=False,
+                   manager_class=DyingManager)
+    d = os.path.join(work, "special_rows", "stage.01.00", list(CASE["sra_listing"])[0])
+    left = sorted(os.listdir(d))
+    assert any(fn.endswith(".tmp") for fn in left)
+    assert sum(1 for fn in left if len(fn) == 8) == stop_after_rows
+    st = pkg.sra.Status(work)
+    assert st.stage == 1 and st.last_special_row == 8192 * stop_after_rows
+    res = pkg.stage1(OracleAligner(oracle), s0, s1, work, sra_limit=200 * 1024, block_pruning=False)
+    assert res["resumed_from"] == 8192 * stop_after_rows
+    _check_against_reference(work, res)
+
+
+def test_partition_bookkeeping(pkg, tmp_path):
+    sra = pkg.sra
+    area = sra.special_rows_path(str(tmp_path), 1, 0)
+    assert area.endswith(os.path.join("special_rows", "stage.01.00"))
+    p = sra.SpecialRowsPartition(area, 100, 200, 1100, 205)
+    assert os.path.basename(p.path) == "00000064.000000C8.0000044C.000000CD"
+    assert p.width_cells == 6 and p.last_row_id() == 100
+    cells = np.arange(12, dtype=np.int32).reshape(6, 2)
+    assert p.write(600, cells[:1]) is False
+    assert os.path.exists(os.path.join(p.path, "000001F4.tmp"))
+    assert os.path.getsize(os.path.join(p.path, "000001F4.tmp")) == 48          # final size from the first write on
+    assert p.write(600, cells[1:4]) is False
+    assert p.write(600, cells[4:]) is True
+    assert sorted(os.listdir(p.path)) == ["000001F4"] and p.last_row_id() == 600
+    assert np.array_equal(p.read_row(600), cells)
+    p.write(900, cells[:3])
+    p.close()
+    q = sra.SpecialRowsPartition(area, 100, 200, 1100, 205)                       # re-open: the .tmp is swept
+    assert sorted(os.listdir(q.path)) == ["000001F4"] and q.rows == [500]
+    i, row = q.continue_from_last_row()
+    assert i == 600 and np.array_equal(row, cells)
+    q.set_border_markers(pkg.INIT_WITH_GAPS, 7, pkg.INIT_WITH_ZEROES, 0)
+    assert {"R00000007.INIT_WITH_GAPS", "C00000000.INIT_WITH_ZEROES"} <= set(os.listdir(q.path))
+    assert sra.flush_interval(20000, 9000, 200 * 1024) == 7032
+    assert sra.flush_interval(20000, 9000, 0) == 0
+
+
+def test_status_file_round_trip(pkg, tmp_path):
+    st = pkg.sra.Status(str(tmp_path))
+    assert not st.loaded
+    st.stage, st.last_special_row = 1, 16384
+    st.save((9004, 9000, 8091))
+    assert open(os.path.join(str(tmp_path), "status")).read() == "1\n16384\n9004 9000 8091\n"
+    assert not os.path.exists(os.path.join(str(tmp_path), "status.tmp"))
+    again = pkg.sra.Status(str(tmp_path))
+    assert again.loaded and (again.stage, again.last_special_row, again.best) == (1, 16384, (9004, 9000, 8091))
