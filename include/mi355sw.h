@@ -49,6 +49,9 @@ typedef struct { int32_t i0, j0, i1, j1; } mi355sw_partition;
 #define MI355SW_ENOMEM (-4)
 #define MI355SW_ETIMEOUT (-5)   /* a bounded in-kernel spin gave up             */
 #define MI355SW_ESTATE (-6)
+#define MI355SW_ETRACEBACK (-8)  /* stage 4: no column of a partition matches its score difference (the crosspoints do
+                                    not lie on one optimal alignment of these sequences)                          */
+#define MI355SW_ETOOLARGE (-9)   /* stage 4: a partition beyond the reference's own limit (131072 columns)         */
 #define MI355SW_EOVERFLOW16 (-7) /* packed 16-bit kernel left its exact range: rerun with force_int32
                                     (mi355sw_align_partition and mi355sw_process_block do that by themselves;
                                     the streaming form reports it from poll/end, rows handed out before are exact) */
@@ -244,6 +247,19 @@ int mi355sw_port_read(mi355sw_handle* h, int32_t row, mi355sw_cell* cells, int32
 int mi355sw_port_local_pointers(mi355sw_handle* h, void** cells, void** counter);
 /* release the inbound port and unmap the outbound one */
 int mi355sw_port_close(mi355sw_handle* h);
+
+/* ---- stage 4: Myers-Miller refinement of the stage-3 crosspoints on the GPU ---------------------------------
+ * Replaces MASA-Core's CPU stage 4 (M/stage4/sw_stage4.cpp:880-960, strategy STAGE_4_STRATEGY_OPTIMIZED =
+ * ort_split_2 :293-380; four pthreads).  `in` = the crosspoints of M/common/CrosspointsFile (crosspoint_03.NN) in
+ * increasing order, absolute 1-based DP coordinates of the sequences given to mi355sw_set_sequences; every
+ * partition between two consecutive crosspoints is cut in the middle of its longer side, over and over, until none
+ * is larger than `max_partition_size` (the reference's --stage-4 limit: 16).  `*out` (free it with mi355sw_free) is
+ * the list MASA-Core writes to crosspoint_04.NN: same points, same order, same tie-breaks. */
+typedef struct { int32_t type, i, j, score; } mi355sw_crosspoint;   /* M/common/Crosspoint.hpp:40-50 */
+typedef struct { int32_t steps; double kernel_ms; int64_t dp_cells; int64_t partitions; } mi355sw_stage4_stats;
+int mi355sw_stage4(mi355sw_handle* h, const mi355sw_crosspoint* in, int32_t count, int32_t max_partition_size,
+                   mi355sw_crosspoint** out, int32_t* out_count, mi355sw_stage4_stats* stats);
+void mi355sw_free(void* p);
 
 /* device enumeration: X/cuda_util.cpp:191-287 (--list-gpus, GPU weights) */
 int mi355sw_device_count(void);

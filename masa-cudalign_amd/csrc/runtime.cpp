@@ -1295,6 +1295,36 @@ int mi355sw_match_last_column(mi355sw_handle* h, const mi355sw_cell* buffer, con
     return MI355SW_OK;
 }
 
+int mi355sw_stage4(mi355sw_handle* h, const mi355sw_crosspoint* in, int32_t count, int32_t max_size, mi355sw_crosspoint** out,
+                   int32_t* out_count, mi355sw_stage4_stats* stats) {
+    if (!h || !in || !out || !out_count || count < 1 || max_size < 1) return MI355SW_EINVAL;
+    if (!h->have_seq) FAIL(h, MI355SW_ESTATE, "stage4 before set_sequences");
+    if (h->active) FAIL(h, MI355SW_ESTATE, "stage4 while a stream is active");
+    for (int k = 0; k < count; k++)
+        if (in[k].i < 0 || in[k].j < 0 || in[k].i > h->len0 || in[k].j > h->len1 || in[k].type < 0 || in[k].type > 2 ||
+            (k > 0 && (in[k].i < in[k - 1].i || in[k].j < in[k - 1].j)))
+            FAIL(h, MI355SW_EINVAL, "crosspoint %d (%d,%d,%d) out of order or out of range", k, in[k].type, in[k].i, in[k].j);
+    HIPCHK(h, hipSetDevice(h->device));
+    std::vector<Stage4Crosspoint> list((size_t) count);
+    for (int k = 0; k < count; k++) { list[(size_t) k].type = in[k].type; list[(size_t) k].i = in[k].i; list[(size_t) k].j = in[k].j; list[(size_t) k].score = in[k].score; }
+    Stage4Stats st{};
+    hipError_t he = hipSuccess;
+    const int rc = stage4_refine((const unsigned char*) h->d_seq0.p, h->len0, (const unsigned char*) h->d_seq1.p, h->len1,
+                                 h->seq0_shift, h->stream, list, max_size, &st, &he);
+    if (rc == -1) FAIL(h, MI355SW_EHIP, "stage 4: %s", hipGetErrorString(he));
+    if (rc == -2) FAIL(h, MI355SW_ETOOLARGE, "stage 4: a partition exceeds 131072 columns; store more special rows in stages 1-3");
+    if (rc < 0) FAIL(h, MI355SW_ETRACEBACK, "stage 4: %s", rc == -3 ? "a partition has no matching column (backtrace lost)" : "a column's scores exceed the partition's score difference");
+    mi355sw_crosspoint* o = (mi355sw_crosspoint*) malloc(sizeof(mi355sw_crosspoint) * list.size());
+    if (!o) FAIL(h, MI355SW_ENOMEM, "stage 4: out of host memory");
+    for (size_t k = 0; k < list.size(); k++) { o[k].type = list[k].type; o[k].i = list[k].i; o[k].j = list[k].j; o[k].score = list[k].score; }
+    *out = o;
+    *out_count = (int32_t) list.size();
+    if (stats) { stats->steps = st.steps; stats->kernel_ms = st.kernel_ms; stats->dp_cells = st.dp_cells; stats->partitions = st.partitions; }
+    return MI355SW_OK;
+}
+
+void mi355sw_free(void* p) { free(p); }
+
 int mi355sw_progress(mi355sw_handle* h, char* buf, size_t len) {
     if (!h || !buf || !len) return MI355SW_EINVAL;
     int done = h->h_pinned ? __atomic_load_n(&h->h_pinned[0], __ATOMIC_RELAXED) : 0;

@@ -4,6 +4,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <vector>
+
 namespace mi355sw {
 
 enum { CHUNK = 64 };   // bus columns staged per hand-off (one per lane)
@@ -176,6 +178,11 @@ hipError_t launch_strip_kernel(const KernelArgs& a, KernelArgs* dargs, int rows_
                                bool sw, bool profile, bool track);
 // packed 16-bit SW kernel (sw_kernel_pk16.inc, instantiated by sw_kernel_pk16_{a,b,c}.hip): strip height = 128*rows_per_half
 hipError_t launch_strip_kernel_pk16(const KernelArgs& a, KernelArgs* dargs, int rows_per_half, int grid, hipStream_t stream, bool track, bool sw);
+// stage 4 (stage4.hip): Myers-Miller refinement of a crosspoint list, batched on the GPU
+struct Stage4Crosspoint { int type, i, j, score; };          // M/common/Crosspoint.hpp
+struct Stage4Stats { int steps; double kernel_ms; long long dp_cells, partitions; };
+int stage4_refine(const unsigned char* d_seq0, long long len0, const unsigned char* d_seq1, long long len1, int seq0_shift,
+                  hipStream_t stream, std::vector<Stage4Crosspoint>& list, int max_size, Stage4Stats* stats, hipError_t* hip_err);
 hipError_t launch_fill_bus(int2* bus, int n, int init_type, int start_offset, hipStream_t stream);
 hipError_t launch_fill_int(int* p, long long count, int value, hipStream_t stream);
 

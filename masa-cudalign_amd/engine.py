@@ -20,7 +20,8 @@ INF = 999999999
 NEEDLEMAN_WUNSCH, SMITH_WATERMAN = 0, 1
 INIT_WITH_ZEROES, INIT_WITH_GAPS, INIT_WITH_CUSTOM_DATA, INIT_WITH_GAPS_OPENED = 0, 1, 2, 3
 
-ERRORS = {-1: "EINVAL", -2: "EHIP", -3: "ENOGPU", -4: "ENOMEM", -5: "ETIMEOUT", -6: "ESTATE", -7: "EOVERFLOW16"}
+ERRORS = {-1: "EINVAL", -2: "EHIP", -3: "ENOGPU", -4: "ENOMEM", -5: "ETIMEOUT", -6: "ESTATE", -7: "EOVERFLOW16",
+          -8: "ETRACEBACK", -9: "ETOOLARGE"}
 
 
 class AlignerError(RuntimeError):
@@ -94,6 +95,10 @@ class StreamParams(C.Structure):
                 ("first_column_resume_rows", C.c_int32)]
 
 
+class Stage4Stats(C.Structure):
+    _fields_ = [("steps", C.c_int32), ("kernel_ms", C.c_double), ("dp_cells", C.c_int64), ("partitions", C.c_int64)]
+
+
 class PortHandle(C.Structure):
     """mi355sw_port_handle: what the owner of a column port sends to the band on its left (hipIpc handle + size)."""
     _fields_ = [("ipc", C.c_ubyte * 64), ("bytes", C.c_int64), ("rows", C.c_int32), ("device", C.c_int32)]
@@ -138,7 +143,8 @@ ABI_SYMBOLS = [
     "mi355sw_stream_read_column", "mi355sw_stream_read_special_row", "mi355sw_stream_read_last_row",
     "mi355sw_stream_abort", "mi355sw_stream_end", "mi355sw_stream_strip_scores",
     "mi355sw_port_create", "mi355sw_port_open", "mi355sw_port_attach", "mi355sw_port_reset", "mi355sw_port_rows_ready", "mi355sw_port_read",
-    "mi355sw_port_local_pointers", "mi355sw_port_close", "mi355sw_device_count", "mi355sw_device_info",
+    "mi355sw_port_local_pointers", "mi355sw_port_close", "mi355sw_stage4", "mi355sw_free",
+    "mi355sw_device_count", "mi355sw_device_info",
 ]
 
 _lib = None
@@ -196,6 +202,10 @@ def load_library():
     lib.mi355sw_port_read.argtypes = [H, C.c_int32, C.c_void_p, C.c_int32]
     lib.mi355sw_port_local_pointers.argtypes = [H, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
     lib.mi355sw_port_close.argtypes = [H]
+    lib.mi355sw_stage4.argtypes = [H, C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_int32),
+                                   C.POINTER(Stage4Stats)]
+    lib.mi355sw_free.argtypes = [C.c_void_p]
+    lib.mi355sw_free.restype = None
     lib.mi355sw_device_info.argtypes = [C.c_int32, C.c_char_p, C.c_size_t, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                         C.POINTER(C.c_int64)]
     _lib = lib
@@ -376,6 +386,18 @@ class MI355Aligner:
         buf = np.empty((max_count, 3), dtype=np.int32)
         cnt = self._lib.mi355sw_stream_strip_scores(self._h, buf.ctypes.data, max_count)
         return buf[:cnt].copy()
+
+    # -- stage 4 (Myers-Miller refinement of the stage-3 crosspoints, M/stage4/sw_stage4.cpp) ------------------
+    def stage4(self, crosspoints, max_partition_size=16):
+        """crosspoints: [(type, i, j, score), ...] as in crosspoint_03.NN; returns (refined list, stats dict)"""
+        cp = np.ascontiguousarray(crosspoints, dtype=np.int32).reshape(-1, 4)
+        out, n, st = C.c_void_p(), C.c_int32(), Stage4Stats()
+        self._check(self._lib.mi355sw_stage4(self._h, cp.ctypes.data, len(cp), max_partition_size, C.byref(out), C.byref(n),
+                                             C.byref(st)), "stage4")
+        buf = (C.c_int32 * (n.value * 4)).from_address(out.value)
+        res = np.frombuffer(buf, dtype=np.int32).reshape(n.value, 4).copy()
+        self._lib.mi355sw_free(out)
+        return [tuple(int(x) for x in r) for r in res], {k: getattr(st, k) for k, _ in Stage4Stats._fields_}
 
     # -- column ports (boundary column GPU to GPU over xGMI) ----------------------------------------
     def portCreate(self, rows):

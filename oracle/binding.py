@@ -56,7 +56,7 @@ _lib = None
 
 def build(force=False):
     if force or not os.path.exists(LIB_PATH) or \
-            os.path.getmtime(LIB_PATH) < os.path.getmtime(os.path.join(HERE, "sw_oracle.c")):
+            os.path.getmtime(LIB_PATH) < max(os.path.getmtime(os.path.join(HERE, f)) for f in ("sw_oracle.c", "stage4_oracle.c")):
         subprocess.check_call(["make", "-C", HERE, "_build/libsworacle.so"], stdout=subprocess.DEVNULL)
     return LIB_PATH
 
@@ -85,6 +85,25 @@ def _u8(a):
     a = np.ascontiguousarray(np.frombuffer(a, dtype=np.uint8) if isinstance(a, (bytes, bytearray)) else a,
                              dtype=np.uint8)
     return a
+
+
+def stage4(seq0, seq1, crosspoints, max_size=16):
+    """MASA-Core stage 4 (stage4_oracle.c): refine [(type, i, j, score), ...] down to partitions <= max_size"""
+    s0, s1 = _u8(seq0), _u8(seq1)
+    cp = np.ascontiguousarray(crosspoints, dtype=np.int32).reshape(-1, 4)
+    out = C.c_void_p()
+    steps = C.c_int()
+    fn = lib().oc_stage4
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int)]
+    fn.restype = C.c_int
+    n = fn(s0.ctypes.data, s1.ctypes.data, cp.ctypes.data, len(cp), max_size, C.byref(out), C.byref(steps))
+    if n < 0:
+        raise RuntimeError("oc_stage4 failed: %d" % n)
+    buf = (C.c_int32 * (n * 4)).from_address(out.value)
+    res = np.frombuffer(buf, dtype=np.int32).reshape(n, 4).copy()
+    lib().oc_stage4_free.argtypes = [C.c_void_p]
+    lib().oc_stage4_free(out)
+    return [tuple(int(x) for x in r) for r in res], steps.value
 
 
 def process_block(seq0, seq1, row, col, i0, j0, i1, j1, recurrence=SMITH_WATERMAN):
@@ -238,6 +257,7 @@ def read_ref_work(work, log=""):
     for st in range(2, 5):
         pth = os.path.join(work, "crosspoints", "crosspoint_%02d.00" % st)
         if os.path.exists(pth):
+            out["crosspoints_%d_txt" % st] = open(pth, "rb").read()
             pts = []
             for ln in open(pth).read().split():
                 if "," in ln:

@@ -107,6 +107,10 @@ def main():
         if case.get("full"):
             rec["alignment_txt_sha256"] = hashlib.sha256(ref["alignment_txt"]).hexdigest()
             rec["crosspoints_2"] = ref.get("crosspoints_2")
+            # stage 3 -> stage 4 (Myers-Miller refinement): the input list, and the output file's digest
+            rec["crosspoints_3"] = ref.get("crosspoints_3")
+            rec["crosspoints_4"] = {"count": len(ref["crosspoints_4"]), "head": ref["crosspoints_4"][:4], "tail": ref["crosspoints_4"][-4:],
+                                    "file_sha256": hashlib.sha256(ref["crosspoints_4_txt"]).hexdigest()}
             rec["special_rows"] = {str(i): cells_digest(a) for (d, i), a in sorted(ref["special_rows"].items())}
         out["cases"].append(rec)
         print(case["name"], rec["best"], flush=True)

@@ -63,3 +63,15 @@ def test_oracle_chain_matches_reference(pkg, oracle):
         run = max(cands, key=lambda t: (t[2], -t[0], -t[1]))
         assert list(run) == ch["band_bests"][k]
     assert list(run) == ch["single_best"]
+
+
+@pytest.mark.parametrize("case", [c for c in G["cases"] if "crosspoints_4" in c], ids=lambda c: c["name"])
+def test_stage4_restatement_reproduces_the_reference_file(case, pkg, oracle):
+    """oracle/stage4_oracle.c (ort_split_2 + the step loop of sw_stage4.cpp) against crosspoint_04.00 as MASA-Core's own
+    CPU stage 4 wrote it: same points, same order -- sha256 of the file text"""
+    import hashlib
+    s0, s1 = make_pair(pkg, case["seq"])
+    pts, steps = oracle.stage4(s0, s1, [tuple(p) for p in case["crosspoints_3"]], 16)
+    txt = "START\n" + "".join("%d,%d,%d,%d\n" % p for p in pts) + "END\n"
+    assert len(pts) == case["crosspoints_4"]["count"]
+    assert hashlib.sha256(txt.encode()).hexdigest() == case["crosspoints_4"]["file_sha256"]
