@@ -143,6 +143,21 @@ void Mi355Aligner::alignPartition(Partition partition) {
     }
 }
 
+int Mi355Aligner::refineCrosspoints(const char* seq0, const char* seq1, int seq0_len, int seq1_len, const int* in_tijs, int count,
+                                    int max_partition_size, int** out_tijs, int* out_count, double* kernel_ms) {
+    setSequences(seq0, seq1, seq0_len, seq1_len);
+    mi355sw_crosspoint* out = NULL;
+    int32_t n = 0;
+    mi355sw_stage4_stats st;
+    memset(&st, 0, sizeof(st));
+    check(mi355sw_stage4(handle, (const mi355sw_crosspoint*) in_tijs, count, max_partition_size, &out, &n, &st), "mi355sw_stage4");
+    unsetSequences();
+    *out_tijs = (int*) out;          /* {type, i, j, score} quadruples; release with mi355sw_free */
+    *out_count = n;
+    if (kernel_ms) *kernel_ms = st.kernel_ms;
+    return st.steps;
+}
+
 #define SELF ((Mi355Aligner*) u)
 int32_t Mi355Aligner::cbRecurrence(void* u) { return SELF->getRecurrenceType(); }
 int32_t Mi355Aligner::cbSpecialInterval(void* u) { return SELF->getSpecialRowInterval(); }

@@ -35,6 +35,13 @@ public:
     virtual const char* getProgressString() const;
     virtual long long getProcessedCells();
 
+    /* Stage 4 on the GPU: what MASA-Core's stage4() (M/stage4/sw_stage4.cpp:880-960) does with the crosspoints of
+     * crosspoint_03.NN, as one call.  `in`/`out` use the core's crosspoint_t (M/common/Crosspoint.hpp); the sequences
+     * must be the ones of the job (setSequences is called here).  A maintainer's stage driver calls this instead of
+     * stage4() when the aligner is a Mi355Aligner; oracle/ref_driver.cpp --gpu-stage4 shows the four lines. */
+    int refineCrosspoints(const char* seq0, const char* seq1, int seq0_len, int seq1_len, const int* in_tijs, int count,
+                          int max_partition_size, int** out_tijs, int* out_count, double* kernel_ms);
+
 private:
     void check(int rc, const char* what);
     /* IManager trampolines (M/libmasa/IManager.hpp:98-313) */

@@ -246,6 +246,7 @@ int main(int argc, char** argv) {
     int split_count = 0, split_step = 0;
     int max_alignments = 1;
     std::string flush_url, load_url;
+    bool gpu_stage4 = false;
     bool do_fork = false;
     std::vector<int> fork_weights;
     std::vector<const char*> files;
@@ -266,6 +267,7 @@ int main(int argc, char** argv) {
         else if (!strncmp(s, "--flush-column=", 15)) { flush_url = s + 15; pruning = false; }
         else if (!strncmp(s, "--load-column=", 14)) { load_url = s + 14; pruning = false; }
         else if (!strncmp(s, "--max-alignments=", 17)) max_alignments = atoi(s + 17);
+        else if (!strcmp(s, "--gpu-stage4")) gpu_stage4 = true;               /* product stage 4 instead of MASA-Core's */
         else if (!strcmp(s, "--fork")) do_fork = true;                       /* weights from IAligner::getForkWeights */
         else if (!strncmp(s, "--fork=", 7)) {                                /* --fork=W1,W2,... (libmasa.cpp:964-980) */
             do_fork = true;
@@ -404,6 +406,29 @@ int main(int argc, char** argv) {
         for (int id = 0; id < count; id++) {
             stage2(job, id);
             stage3(job, id);
+#ifdef USE_MI355_ALIGNER
+            if (gpu_stage4) {
+                /* what stage4() does (sw_stage4.cpp:880-960), with the refinement itself on the GPU */
+                Timer t4; int ev = t4.createEvent("GPU_STAGE4"); t4.init();
+                CrosspointsFile in3(job->getCrosspointFile(STAGE_3, id));
+                in3.loadCrosspoints();
+                std::vector<int> tijs;
+                for (size_t k = 0; k < in3.size(); k++) { tijs.push_back(in3[k].type); tijs.push_back(in3[k].i); tijs.push_back(in3[k].j); tijs.push_back(in3[k].score); }
+                Sequence* q0 = job->getAlignmentParams()->getSequence(0);
+                Sequence* q1 = job->getAlignmentParams()->getSequence(1);
+                int* out = NULL; int n = 0; double kms = 0;
+                int steps = aligner->refineCrosspoints(q0->getData(false), q1->getData(false), q0->getInfo()->getSize(), q1->getInfo()->getSize(),
+                                                       tijs.data(), (int) in3.size(), job->stage4_maximum_partition_size, &out, &n, &kms);
+                CrosspointsFile out4(job->getCrosspointFile(STAGE_4, id));
+                for (int k = 0; k < n; k++) { crosspoint_t c; c.type = out[4 * k]; c.i = out[4 * k + 1]; c.j = out[4 * k + 2]; c.score = out[4 * k + 3]; out4.push_back(c); }
+                out4.save();
+                mi355sw_free(out);
+                float ms = t4.eventRecord(ev);
+                FILE* st4 = job->fopenStatistics(STAGE_4, id);
+                fprintf(st4, "GPU STAGE 4 (mi355sw_stage4): steps %d  crosspoints %d -> %d  kernels %.3f ms  total %.3f ms\n", steps, (int) in3.size(), n, kms, ms);
+                fclose(st4);
+            } else
+#endif
             stage4(job, id);
             stage5(job, id);
             stage6(job, id);

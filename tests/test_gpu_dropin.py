@@ -168,3 +168,17 @@ def test_fork_chain_through_masa_core(pkg, oracle):
     log, forks = _run_forked(pkg, ch["seq"], ["--stage-1", "--no-flush", "--fork"])
     assert "fork[0+]: 100.00%" in log and len(forks) == 1
     assert list(forks[0]["best"]) == ch["single_best"]
+
+
+@pytest.mark.parametrize("name", ["full_pipeline_20000x9000_b8192", "full_pipeline_pruned_60000x50000_b8192"])
+def test_full_pipeline_with_stage4_on_the_gpu(pkg, oracle, name):
+    """MASA-Core's stages 1-3 and 5-6 with the engine as aligner AND the product's stage 4 (mi355sw_stage4 through
+    Mi355Aligner::refineCrosspoints) in place of MASA-Core's CPU stage 4: crosspoint_04.00 and alignment.00.txt are
+    the reference's, byte for byte."""
+    case = [c for c in G["cases"] if c["name"] == name][0]
+    disk = [a for a in case["args"] if a.startswith("--disk-size")]
+    out = _run(pkg, oracle, case["seq"], disk + ["--strip-rows=1024", "--gpu-stage4"])
+    assert list(out["best"]) == case["best"]
+    assert "GPU STAGE 4" in out["statistics"]["statistics_04.00"]
+    assert hashlib.sha256(out["crosspoints_4_txt"]).hexdigest() == case["crosspoints_4"]["file_sha256"]
+    assert hashlib.sha256(out["alignment_txt"]).hexdigest() == case["alignment_txt_sha256"]

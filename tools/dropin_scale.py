@@ -2,7 +2,7 @@
 engine as its aligner, on a pair too large for the reference's CPU aligner: per-stage times from the reference's
 own statistics files, and self-consistency of the result (the alignment that stage 6 prints re-scores to the best
 score stage 1 reported; stage-2 crosspoints start/end where stage 1 says the alignment ends).
-  python tools/dropin_scale.py m n [disk-size] [out.json]
+  python tools/dropin_scale.py m n [disk-size] [out.json]        (DROPIN_EXTRA="--gpu-stage4 ..." adds options)
 This is test infrastructure (it runs a binary from oracle/_ref); the product is the library behind it."""
 import json, os, re, shutil, subprocess, sys, tempfile, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -51,7 +51,9 @@ def main():
         work = os.path.join(tmp, "work")
         t0 = time.time()
         p = subprocess.run([os.path.join(g.ROOT, "oracle", "_ref", "masa_mi355"), "--work-dir=" + work,
-                            "--disk-size=" + disk, f0, f1], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, cwd=tmp)
+                            "--disk-size=" + disk] + os.environ.get("DROPIN_EXTRA", "").split() + [f0, f1],
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, cwd=tmp)
+        res["extra_options"] = os.environ.get("DROPIN_EXTRA", "")
         res["wall_s"] = time.time() - t0
         res["returncode"] = p.returncode
         log = p.stdout.decode(errors="replace")
@@ -73,7 +75,14 @@ def main():
             pts = out.get("crosspoints_%d" % st)
             if pts:
                 res["crosspoints_%d" % st] = {"count": len(pts), "first": list(pts[0]), "last": list(pts[-1])}
+        import hashlib
+        if "crosspoints_4_txt" in out:
+            res["crosspoint_04_sha256"] = hashlib.sha256(out["crosspoints_4_txt"]).hexdigest()
+        gl = [ln for ln in out.get("statistics", {}).get("statistics_04.00", "").splitlines() if ln.startswith("GPU STAGE 4")]
+        if gl:
+            res["gpu_stage4"] = gl[0]
         if "alignment_txt" in out:
+            res["alignment_sha256"] = hashlib.sha256(out["alignment_txt"]).hexdigest()
             sc, length, gaps = rescore(out["alignment_txt"])
             res["alignment"] = {"bytes": len(out["alignment_txt"]), "columns": length, "gap_columns": gaps, "rescored": sc}
             res["rescore_equals_best"] = (sc == res["best"][2]) if (sc is not None and res["best"]) else None
