@@ -193,6 +193,17 @@ def main():
                         segment_rows=1 << 15, transport=comm)
     if world > 1:
         runner.reduce_best = lambda b, _r=runner: _reduce_cpu(dist, b, world, coll_device)
+    comm_note = None
+    if world > 1 and comm == "p2p":
+        # every rank creates its column port and maps its neighbour's once, before anything is timed; if any rank
+        # cannot (no peer access between two of the GPUs, IPC refused), ALL ranks use the host transport instead
+        ok = torch.tensor([1 if runner.probe_p2p(m) else 0], dtype=torch.int32, device=coll_device)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0:
+            comm_note = "p2p unavailable (%s): pinned host columns + gloo instead" % (runner.p2p_error or "a neighbour rank failed")
+            comm = "host"
+            runner.transport = "host"
+            al.portClose()
 
     def one_step():
         best = runner.run(m, j0, j1)
@@ -243,7 +254,7 @@ def main():
                         % (args.tall, args.size * args.tall, world, n, world, n // world, comm)),
                        "m": m, "n": n, "bands": world, "strip_rows": st["strip_rows"], "waves_per_gpu": st["waves"],
                        "kernel": {2: "pk16", 1: "int32-profile", 0: "int32-generic"}[st["profile_kernel"]],
-                       "comm": comm if world > 1 else "none", "kernel_build_id": kernel_build_id()},
+                       "comm": comm if world > 1 else "none", "comm_note": comm_note, "kernel_build_id": kernel_build_id()},
             "best": {"i": best[0] + 1, "j": best[1] + 1, "score": best[2]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,

@@ -88,6 +88,7 @@ class BandRunner:
         self._in_rows = 0
         self._out_token = None       # handle bytes of the neighbour's port currently mapped
         self.restarts = 0            # packed-kernel overflow restarts (int32 rerun) of the last run
+        self.p2p_error = None        # why probe_p2p() failed on this rank
 
     def _tensor(self, rows):
         import torch
@@ -115,6 +116,47 @@ class BandRunner:
             if b != self._out_token:
                 eng.portOpen(PortHandle.frombytes(b))
                 self._out_token = b
+
+    def probe_p2p(self, m):
+        """One port hand-shake without a run, errors caught: True if this rank could create its inbound port and map
+        its neighbour's.  The caller makes the ranks agree (all_reduce MIN) and falls back to transport="host" for
+        everybody if any of them could not -- a rank that finds out in the middle of run() would leave its
+        neighbours' kernels waiting."""
+        if self.transport != "p2p":
+            return True
+        from .engine import AlignerError
+        ok = True
+        import torch
+        first, last = self.rank == 0, self.rank == self.world - 1
+        from .engine import PortHandle
+        size = len(PortHandle().tobytes())
+        try:
+            if not first:
+                try:
+                    self._in_port, self._in_rows = self.engine.portCreate(m), m
+                    tok = torch.frombuffer(bytearray(self._in_port.tobytes()), dtype=torch.uint8).clone()
+                except AlignerError as e:
+                    self.p2p_error = str(e)
+                    ok = False
+                    tok = torch.zeros(size, dtype=torch.uint8)
+                self.dist.send(tok, dst=self.rank - 1)
+            if not last:
+                tok = torch.empty(size, dtype=torch.uint8)
+                self.dist.recv(tok, src=self.rank + 1)
+                b = bytes(tok.numpy().tobytes())
+                if not any(b):
+                    ok = False
+                else:
+                    try:
+                        self.engine.portOpen(PortHandle.frombytes(b))
+                        self._out_token = b
+                    except AlignerError as e:
+                        self.p2p_error = str(e)
+                        ok = False
+        except Exception as e:            # transport of the tokens itself failed
+            self.p2p_error = str(e)
+            ok = False
+        return ok
 
     def run(self, m, j0, j1, recurrence=SMITH_WATERMAN, track_best=True, first_row_init_type=INIT_WITH_ZEROES,
             first_col_init_type=INIT_WITH_ZEROES, poll_sleep=0.0005, want_last_row=False, before_end=None,
