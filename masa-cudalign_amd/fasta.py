@@ -37,7 +37,12 @@ class Sequence:
     """forward data + the view the modifiers select"""
 
     def __init__(self, description, forward, modifiers):
-        self.description, self.forward, self.modifiers = description, forward, modifiers
+        self.raw_description = description
+        # SequenceInfo::setDescription (M/common/biology/SequenceInfo.cpp:56-67): without the '>' and the line end
+        d = description[1:] if description.startswith(">") else description
+        nl = d.find("\n")
+        self.description = d[:nl] if nl >= 0 else d
+        self.forward, self.modifiers = forward, modifiers
         self.original_size = len(forward)
         t0 = modifiers.trim_start if modifiers.trim_start > 0 else 1
         t1 = modifiers.trim_end if modifiers.trim_end > 0 else len(forward)

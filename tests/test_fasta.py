@@ -11,7 +11,7 @@ def test_normalisation_rules(pkg):
     from masa_cudalign_amd import fasta
     raw = b">chr test  with blanks\r\nacgtN nryk\r\n\r\nAC GT\nnn\n"
     s = fasta.parse(raw)
-    assert s.description == ">chr test  with blanks\r\n"
+    assert s.raw_description == ">chr test  with blanks\r\n" and s.description == "chr test  with blanks\r"
     assert s.forward.tobytes() == b"ACGTNNRYKACGTNN" and s.original_size == 15 and len(s) == 15
     c = fasta.parse(raw, fasta.SequenceModifiers(complement=True))
     assert c.forward.tobytes() == b"TGCANNRYKTGCANN"
