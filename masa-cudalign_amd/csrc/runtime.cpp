@@ -330,13 +330,17 @@ static double estimate_ns(int m, int n, int R, int W) {
     return step * ((double) rounds * n + 280.0 * hops);
 }
 
-static int pick_rows_per_lane(const mi355sw_handle* h, int m, int n, bool packed) {
+static int pick_rows_per_lane(const mi355sw_handle* h, int m, int n, bool packed, bool special_rows) {
     if (h->cfg.rows_per_lane == 4 || h->cfg.rows_per_lane == 8 || h->cfg.rows_per_lane == 12 ||
         h->cfg.rows_per_lane == 16 || h->cfg.rows_per_lane == 24 || h->cfg.rows_per_lane == 32)
         return h->cfg.rows_per_lane;
-    static const int cand16[] = {4, 8, 12, 16, 24, 32}, cand32[] = {4, 8, 16};
-    const int* cand = packed ? cand16 : cand32;
-    const int nc = packed ? 6 : 3;
+    // Special rows sit on multiples of the strip height.  With a height that divides 8192 they fall on CUDAlign's
+    // own grid (multiples of MINIMUM_FLUSH_INTERVAL, AbstractDiagonalAligner.cpp:35), so an area written here can be
+    // continued or read by a run of the reference and vice versa; 768- and 1536-row strips are only chosen when no
+    // special rows are asked for (they are 1-2 % faster on some shapes).
+    static const int cand16[] = {4, 8, 12, 16, 24, 32}, cand32[] = {4, 8, 16}, cand16p2[] = {4, 8, 16, 32};
+    const int* cand = packed ? (special_rows ? cand16p2 : cand16) : cand32;
+    const int nc = packed ? (special_rows ? 4 : 6) : 3;
     const int W = h->cfg.waves > 0 ? h->cfg.waves : h->compute_units * 4;
     int best = cand[0];
     double tb = estimate_ns(m, n, best, W);
@@ -370,7 +374,7 @@ int mi355sw_stream_begin(mi355sw_handle* h, const mi355sw_partition* part, const
     {
         const bool will16 = h->packed_ok && !p->force_int32 &&
                             !(h->cfg.flags & MI355SW_F_FORCE_INT32);
-        h->R = pick_rows_per_lane(h, m, n, will16);
+        h->R = pick_rows_per_lane(h, m, n, will16, p->special_row_interval > 0);
         // the int32 kernels are instantiated for R in {4,8,16}
         if (!will16 && h->R != 4 && h->R != 8 && h->R != 16) h->R = h->R > 16 ? 16 : 8;
     }
