@@ -65,7 +65,16 @@ def report(path):
             for t in b[3]:
                 if t in idx and idx[t] <= i:
                     loops.add((idx[t], i))
-        print("function %s: %d instructions, %d scratch loads/stores in total" % (fname, sum(b[1] for b in blocks), sum(b[2] for b in blocks)))
+        total = sum(b[2] for b in blocks)
+        # callee-saved registers of the noinline strip function: stored at its entry, reloaded at its exit -- once per strip
+        big = [(h, t) for (h, t) in loops if sum(blocks[k][1] for k in range(h, t + 1)) > 1500]
+        first_loop = min(h for h, _ in big) if big else 0
+        last_loop = max(t for _, t in big) if big else len(blocks) - 1
+        pro = sum(b[2] for b in blocks[:first_loop])
+        epi = sum(b[2] for b in blocks[last_loop + 1:])
+        print("function %s: %d instructions, %d scratch loads/stores in total: %d before the first chunk loop (callee-saved "
+              "registers stored, once per strip), %d after the last one (reloaded, once per strip), %d in between"
+              % (fname, sum(b[1] for b in blocks), total, pro, epi, total - pro - epi))
         for (h, t) in sorted(loops):
             ins = sum(blocks[k][1] for k in range(h, t + 1))
             sc = sum(blocks[k][2] for k in range(h, t + 1))
