@@ -20,10 +20,49 @@ class OracleStreamEngine:
 
     def __init__(self, oracle, seq0, seq1, seg=256):
         self.o, self.s0, self.s1, self.seg = oracle, seq0, seq1, seg
+        self.in_shm = self.out_shm = None
+
+    # -- column ports, stood in by POSIX shared memory between the rank processes: int32 row counter at +0, cells from
+    #    +256 -- the layout of the engine's port (csrc/runtime.cpp); the "kernel" below publishes and polls like
+    #    complete_strip_common / claim_strip_common do
+    def portCreate(self, rows):
+        from multiprocessing import shared_memory
+        from masa_cudalign_amd.engine import PortHandle
+        if self.in_shm is not None:
+            self.in_shm.close(); self.in_shm.unlink()
+        self.in_shm = shared_memory.SharedMemory(create=True, size=256 + 8 * (rows + 1))
+        self.in_shm.buf[:256] = bytes(256)
+        ph = PortHandle()
+        name = self.in_shm.name.encode()
+        for k, b in enumerate(name):
+            ph.ipc[k] = b
+        ph.rows, ph.bytes = rows, 256 + 8 * (rows + 1)
+        return ph
+
+    def portReset(self):
+        self.in_shm.buf[:4] = bytes(4)
+
+    def portOpen(self, ph):
+        from multiprocessing import shared_memory
+        name = bytes(ph.ipc).split(b"\0")[0].decode()
+        if self.out_shm is not None:
+            self.out_shm.close()
+        self.out_shm = shared_memory.SharedMemory(name=name)
+
+    def portClose(self):
+        if self.out_shm is not None:
+            self.out_shm.close(); self.out_shm = None
+        if self.in_shm is not None:
+            self.in_shm.close(); self.in_shm.unlink(); self.in_shm = None
+
+    def _port_rows(self):
+        return int(np.frombuffer(self.in_shm.buf, dtype=np.int32, count=1)[0])
 
     def streamBegin(self, part, recurrence_type=1, track_best=True, first_row_init_type=0, first_row_start_offset=0,
-                    want_last_column=False, first_column_init_type=0, stream_first_column=False, first_column=None, **kw):
+                    want_last_column=False, first_column_init_type=0, stream_first_column=False, first_column=None,
+                    first_column_port=False, last_column_port=False, **kw):
         o = self.o
+        self.from_port, self.to_port = first_column_port, last_column_port
         self.part, self.rec = part, recurrence_type
         self.m, self.n = part.i1 - part.i0, part.j1 - part.j0
         self.row = o.initial_cells(first_row_init_type, first_row_start_offset, self.n + 1)
@@ -31,7 +70,7 @@ class OracleStreamEngine:
         self.col = np.zeros((self.m + 1, 2), dtype=np.int32)
         if self.custom_col:
             self.col[0] = first_column[0]
-            self.fed = 0 if stream_first_column else self.m
+            self.fed = 0 if (stream_first_column or first_column_port) else self.m
         else:
             self.col[:] = o.initial_cells(first_column_init_type, 0, self.m + 1)
             self.fed = self.m
@@ -49,6 +88,13 @@ class OracleStreamEngine:
         o = self.o
         while self.done < self.m:
             r1 = min(self.done + self.seg, self.m)
+            if self.from_port and self.fed < r1:
+                ready = self._port_rows()               # what the neighbour's "kernel" has published so far
+                if ready > self.fed:
+                    cells = np.frombuffer(self.in_shm.buf, dtype=np.int32, count=2 * (ready - self.fed),
+                                          offset=256 + 8 * (self.fed + 1)).reshape(-1, 2)
+                    self.col[1 + self.fed:1 + ready] = cells
+                    self.fed = ready
             if self.fed < r1:
                 return
             r0 = self.done
@@ -58,6 +104,10 @@ class OracleStreamEngine:
                            want_last_row=True, want_last_col=True, block_h=64, block_w=128)
             self.row = res["last_row"]
             self.last_col[r0:r1] = res["last_col"][1:]
+            if self.to_port:                             # cells first, then the row count (the release store)
+                dst = np.frombuffer(self.out_shm.buf, dtype=np.int32, count=2 * (r1 - r0), offset=256 + 8 * (r0 + 1)).reshape(-1, 2)
+                dst[:] = res["last_col"][1:]
+                np.frombuffer(self.out_shm.buf, dtype=np.int32, count=1)[0] = r1
             b = res["best"]
             if b[0] >= 0:
                 self.cands.append((b[0] - 1 + r0 + self.part.i0, b[1] - 1 + self.part.j0, b[2]))
@@ -84,7 +134,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, m, n, q):
+def _worker(rank, world, port, m, n, q, transport="host"):
     sys.path.insert(0, ROOT)
     import __graft_entry__ as graft
     pkg = graft.load_package()
@@ -97,22 +147,31 @@ def _worker(rank, world, port, m, n, q):
         s0, s1 = pkg.seqgen.related_pair(m, n, cfg=41)
         lim = band_limits(n, [1] * world)
         eng = OracleStreamEngine(oracle, s0, s1, seg=200)
-        runner = BandRunner(eng, dist=dist, rank=rank, world=world, device=None, segment_rows=300)
-        best = runner.run(m, lim[rank], lim[rank + 1])
-        gbest = runner.reduce_best(best)
-        q.put((rank, tuple(best), tuple(gbest)))
+        runner = BandRunner(eng, dist=dist, rank=rank, world=world, device=None, segment_rows=300, transport=transport)
+        if transport == "p2p":
+            assert runner.probe_p2p(m)
+        out = []
+        for rep in range(2 if transport == "p2p" else 1):     # second run: port re-used (owner resets, then tells the writer)
+            best = runner.run(m, lim[rank], lim[rank + 1])
+            out.append((tuple(best), tuple(runner.reduce_best(best))))
+        dist.barrier()
+        eng.portClose()
+        q.put((rank, out))
     finally:
         dist.destroy_process_group()
 
 
 @pytest.mark.timeout(300)
-@pytest.mark.parametrize("world", [2, 3, 4])       # 3 and 4: middle bands receive and send at the same time
-def test_bands_over_gloo(pkg, oracle, world):
+@pytest.mark.parametrize("world,transport", [(2, "host"), (3, "host"), (4, "host"), (2, "p2p"), (4, "p2p")])
+def test_bands_over_gloo(pkg, oracle, world, transport):
+    """3 and 4 bands: middle bands receive and send at the same time.  "p2p": the driver's column-port protocol
+    (probe, handle exchange before every run, reset by the owner, publish / poll of the row counter) with the ports
+    stood in by shared memory between the rank processes."""
     m, n = 1500, 1800
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, m, n, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, m, n, q, transport)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=240) for _ in range(world)]
@@ -122,8 +181,9 @@ def test_bands_over_gloo(pkg, oracle, world):
     s0, s1 = pkg.seqgen.related_pair(m, n, cfg=41)
     ref = oracle.stage1(s0, s1)
     want = (ref["best"][0] - 1, ref["best"][1] - 1, ref["best"][2])   # 0-based cell, as the engine reports
-    for rank, best, gbest in res:
-        assert gbest == want, (rank, best, gbest, want)
+    for rank, out in res:
+        for best, gbest in out:
+            assert gbest == want, (rank, best, gbest, want)
 
 
 def _worker_nw(rank, world, port, m, n, q):
