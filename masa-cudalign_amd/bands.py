@@ -124,11 +124,10 @@ class BandRunner:
         neighbours' kernels waiting."""
         if self.transport != "p2p":
             return True
-        from .engine import AlignerError
-        ok = True
         import torch
+        from .engine import AlignerError, PortHandle
+        ok = True
         first, last = self.rank == 0, self.rank == self.world - 1
-        from .engine import PortHandle
         size = len(PortHandle().tobytes())
         try:
             if not first:
