@@ -266,11 +266,18 @@ def main():
                          "note": "scan kernel: 17 B per column per %d-row strip; the binding unit is VALU issue" % st["strip_rows"]},
             "valu_roofline": _valu(st, band_cells, k_ms, pmc),
         }
+        # the extras must never cost the headline line: whatever goes wrong in them is reported inside the JSON
         if world == 1 and not args.no_target_shape:
-            out["target_shape"] = target_shape(pkg, local_rank, check=not args.no_cpu_baseline)
+            try:
+                out["target_shape"] = target_shape(pkg, local_rank, check=not args.no_cpu_baseline)
+            except Exception as e:                       # noqa: BLE001
+                out["target_shape"] = {"error": "%s: %s" % (type(e).__name__, e)}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(pkg)
-            out["cpu_baseline_all_cores"] = cpu_baseline_mt(pkg)
+            for key, fn in (("cpu_baseline", cpu_baseline), ("cpu_baseline_all_cores", cpu_baseline_mt)):
+                try:
+                    out[key] = fn(pkg)
+                except Exception as e:                   # noqa: BLE001
+                    out[key] = {"error": "%s: %s" % (type(e).__name__, e)}
         print(json.dumps(out), flush=True)
     al.close()
     if world > 1:
