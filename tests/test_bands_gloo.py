@@ -186,6 +186,58 @@ def test_bands_over_gloo(pkg, oracle, world, transport):
             assert gbest == want, (rank, best, gbest, want)
 
 
+def _worker_fallback(rank, world, port, m, n, q):
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as graft
+    pkg = graft.load_package()
+    oracle = graft.load_oracle()
+    from masa_cudalign_amd.bands import BandRunner, band_limits
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        s0, s1 = pkg.seqgen.related_pair(m, n, cfg=41)
+        lim = band_limits(n, [1] * world)
+        eng = OracleStreamEngine(oracle, s0, s1, seg=200)
+        if rank == 1:                                  # this rank's GPU "cannot" export its port
+            def broken(rows):
+                raise OSError("hipIpcGetMemHandle: invalid argument")
+            eng.portCreate = broken
+        runner = BandRunner(eng, dist=dist, rank=rank, world=world, device=None, segment_rows=300, transport="p2p")
+        mine = runner.probe_p2p(m)
+        ok = torch.tensor([1 if mine else 0], dtype=torch.int32)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)      # what bench.py does: everybody or nobody
+        if int(ok.item()) == 0:
+            runner.transport = "host"
+            eng.portClose()
+        best = runner.run(m, lim[rank], lim[rank + 1])
+        q.put((rank, mine, int(ok.item()), tuple(runner.reduce_best(best))))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_p2p_probe_failure_falls_back_to_host_for_everybody(pkg, oracle):
+    """one rank cannot create its column port: its probe fails, its left neighbour gets an empty token and fails too,
+    the third rank succeeds -- and after the all_reduce all three use the host transport and the chain's answer is right"""
+    m, n, world = 1200, 1500, 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_fallback, args=(r, world, port, m, n, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {r[0]: r[1:] for r in (q.get(timeout=240) for _ in range(world))}
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    s0, s1 = pkg.seqgen.related_pair(m, n, cfg=41)
+    ref = oracle.stage1(s0, s1)
+    want = (ref["best"][0] - 1, ref["best"][1] - 1, ref["best"][2])
+    assert [res[r][0] for r in range(world)] == [False, False, True]
+    assert all(res[r][1] == 0 and res[r][2] == want for r in range(world))
+
+
 def _worker_nw(rank, world, port, m, n, q):
     sys.path.insert(0, ROOT)
     import __graft_entry__ as graft
