@@ -31,6 +31,18 @@ class InitialCellsReader:
     def getType(self):
         return self.type
 
+    def getStartOffset(self):
+        return self.start_offset
+
+    def seek(self, position):           # InitialCellsReader.cpp:57-59: relative to the start offset
+        self.position = self.start_offset + position
+
+    def getOffset(self):
+        return self.position - self.start_offset
+
+    def clone(self, offset):            # :65-71
+        return InitialCellsReader(self.gap_open, self.gap_ext, self.start_offset + offset)
+
     def read(self, buf, length):
         if buf is None:                 # skip `length` cells (SpecialRowsPartition::continueFromLastRow reads into NULL)
             self.position += length
@@ -58,10 +70,70 @@ class ArrayCellsReader:
     def getType(self):
         return INIT_WITH_CUSTOM_DATA
 
+    def seek(self, position):
+        self.position = position
+
+    def getOffset(self):
+        return self.position
+
     def read(self, buf, length):
         if buf is not None:
             buf[:length] = self.cells[self.position:self.position + length]
         self.position += length
+        return length
+
+
+class FileCellsReader:
+    """M/common/io/FileCellsReader.cpp: a border kept in a file of 8-byte cells (C00000000.INIT_WITH_CUSTOM_DATA)"""
+
+    def __init__(self, filename):
+        self.filename = filename
+        self.position = 0
+
+    def getType(self):
+        return INIT_WITH_CUSTOM_DATA
+
+    def seek(self, position):
+        self.position = position
+
+    def getOffset(self):
+        return self.position
+
+    def read(self, buf, length):
+        if buf is not None:
+            a = np.fromfile(self.filename, dtype=np.int32, count=2 * length, offset=8 * self.position).reshape(-1, 2)
+            if a.shape[0] != length:
+                raise RuntimeError("%s: %d cells at %d, file ends after %d" % (self.filename, length, self.position, a.shape[0]))
+            buf[:length] = a
+        self.position += length
+        return length
+
+
+class ReversedCellsReader:
+    """M/common/io/ReversedCellsReader.cpp:46-72: reads a seekable border backwards from the position it was seeked to;
+    every read returns the cells in reversed order"""
+
+    def __init__(self, reader):
+        self.reader = reader
+        self.position = 0
+
+    def getType(self):
+        return INIT_WITH_CUSTOM_DATA
+
+    def seek(self, position):
+        self.position = position
+
+    def getOffset(self):
+        return self.position
+
+    def read(self, buf, length):
+        length = min(length, self.position)
+        self.position -= length
+        self.reader.seek(self.position)
+        if buf is not None and length > 0:
+            tmp = np.empty((length, 2), dtype=np.int32)
+            self.reader.read(tmp, length)
+            buf[:length] = tmp[::-1]
         return length
 
 
@@ -221,7 +293,10 @@ class Stage1Manager:
         return self.best_location == AT_SEQUENCE_1_AND_2
 
     def mustDispatchLastRow(self):
-        # a special-rows partition always takes the last row too (SpecialRowsPartition hands out a last-row writer)
+        # the native driver always saves the partition's last row next to the special rows: it is what marks stage 1
+        # as complete for a later run (sw_stage1.cpp:210-214 tests getLastRowId() == i1; MASA-Core itself only has that
+        # row when the last block row happens to be a special one).  Stage 2 never reads it: it lies below every
+        # crosspoint (SpecialRowsPartition::nextSpecialRow wants a row ABOVE)
         return self.keep_last_row or self.sra is not None or self.best_location in (AT_SEQUENCE_1, AT_SEQUENCE_1_OR_2)
 
     def mustDispatchLastColumn(self):
@@ -248,3 +323,244 @@ class Stage1Manager:
 
     def lastColumn(self):
         return np.concatenate(self.last_column_chunks, axis=0)
+
+
+START_TYPE_MATCH, START_TYPE_GAP_H, START_TYPE_GAP_V = 0, 1, 2       # IManager.hpp:52-58 (= the crosspoint types)
+MATCH_ALIGNED, MATCH_GAPPED = 0, 1                                    # libmasaTypes.hpp:66-72
+
+
+class BacktraceLost(RuntimeError):
+    """the reference prints "Backtrace lost" and exits: a border sum above the goal, or a partition swept to its end
+    without meeting the goal"""
+
+
+class AlignerManager:
+    """MASA-Core's AlignerManager as the traceback stages use it (M/common/AlignerManager.cpp): one object that lives
+    through a stage, gets sequences, borders, a goal score and the special row / first column to match it against,
+    runs partitions on the aligner and reports where the optimal alignment leaves each of them.
+
+    The aligner sees coordinates relative to the sub-sequences handed to setSequences(); everything the stages see is
+    absolute (seq offsets added back, :336, :375, :414-415)."""
+
+    def __init__(self, aligner):
+        self.aligner = aligner
+        self.recurrence = SMITH_WATERMAN
+        self.block_pruning = False
+        self.special_row_interval = 0
+        self.sra = None
+        self.seq0_offset = self.seq1_offset = 0
+        self.first_row_reader = self.first_column_reader = None
+        self.last_column_reader = self.last_row_reader = None
+        self.last_column_writer = self.last_row_writer = None
+        self.goal_score, self.goal_location = -INF, AT_NOWHERE
+        self.best_list, self.best_location = None, AT_NOWHERE
+        self.super_partition = None
+        self.partition = None
+        self.start_type = START_TYPE_MATCH
+        self.found = False
+        self.next_crosspoint = None          # (i, j, score, type)
+        self.active = False
+        self.last_column_pos = self.last_row_pos = 0
+
+    # -- configuration (:191-316) ------------------------------------------------------------------------------
+    def setSequences(self, seq0, seq1, i0, j0, i1, j1):
+        self.seq0_offset, self.seq1_offset = i0, j0
+        self.aligner.setSequences(seq0[i0:i1], seq1[j0:j1])
+
+    def unsetSequences(self):
+        self.aligner.unsetSequences()
+
+    def setRecurrenceType(self, r):
+        self.recurrence = r
+
+    def setBlockPruning(self, b):
+        self.block_pruning = b
+
+    def setSpecialRowInterval(self, n):
+        self.special_row_interval = int(n)
+
+    def setSpecialRowsPartition(self, p):
+        self.sra = p
+
+    def setLastColumnReader(self, r):
+        self.last_column_reader = r
+
+    def setLastRowReader(self, r):
+        self.last_row_reader = r
+
+    def setGoalScore(self, score, location):
+        if score == -INF or location == AT_NOWHERE:
+            self.unsetGoalScore()
+        else:
+            self.goal_score, self.goal_location = score, location
+
+    def unsetGoalScore(self):
+        self.goal_score, self.goal_location = -INF, AT_NOWHERE
+
+    # -- one partition (:89-166) -------------------------------------------------------------------------------
+    def alignPartition(self, partition, start_type):
+        self.partition, self.start_type, self.found = partition, start_type, False
+        if partition.getWidth() == 0 or partition.getHeight() == 0:
+            return
+        self.last_column_pos = self.last_row_pos = 0
+        self.active = True
+        if self.sra is not None:
+            self.first_row_reader, self.first_column_reader = self.sra.first_row_reader, self.sra.first_column_reader
+            self.last_column_writer, self.last_row_writer = self.sra.last_column_writer, self.sra.last_row_writer
+        if self.goal_location in (AT_SEQUENCE_2, AT_SEQUENCE_1_OR_2):
+            r = self._find_full_gap(partition.getWidth(), start_type != START_TYPE_GAP_H, self.last_column_reader)
+            if r is not None:
+                self.next_crosspoint = (partition.i0, partition.j1, r, 1)
+                self.active = False
+        if self.goal_location in (AT_SEQUENCE_1, AT_SEQUENCE_1_OR_2):
+            r = self._find_full_gap(partition.getHeight(), start_type != START_TYPE_GAP_V, self.last_row_reader)
+            if r is not None:
+                self.next_crosspoint = (partition.i1, partition.j0, r, 2)
+                self.active = False
+        if self.active:
+            adj = Partition(partition.i0 - self.seq0_offset, partition.j0 - self.seq1_offset,
+                            partition.i1 - self.seq0_offset, partition.j1 - self.seq1_offset)
+            self.aligner.alignPartition(adj, self)
+
+    def isFoundCrosspoint(self):
+        return self.found
+
+    def getNextCrosspoint(self):
+        return self.next_crosspoint if self.found else (-1, -1, -INF, 0)
+
+    # -- goal matching (:625-718) ------------------------------------------------------------------------------
+    def _find_goal_cell(self, buf, length, reader):
+        """first cell k of the dispatched border chunk whose forward value (from `reader`: the special row / first
+        column of the stage before, read backwards) and reverse value (buf) add up to the goal"""
+        if self.found or reader is None:
+            return None
+        base = np.empty((length, 2), dtype=np.int32)
+        got = reader.read(base, length)
+        r = self.aligner.matchLastColumn(buf[:got], base[:got], self.goal_score)
+        if r["found"]:
+            self.found = True
+            return r
+        if r["type"] < 0:
+            raise BacktraceLost("backtrace lost (%d): border sum above the goal %d at cell %d of a chunk of %d"
+                                % (r["type"], self.goal_score, r["k"], length))
+        return None
+
+    def _find_full_gap(self, length, open_gap, reader):
+        """(:659-676) the partition crossed by one gap run: the border cell the run comes from, its gap component plus
+        the run, equals the goal"""
+        if self.found or reader is None:
+            return None
+        first_f = -length * GAP_EXT - (GAP_OPEN if open_gap else 0)
+        cell = np.empty((1, 2), dtype=np.int32)
+        off = reader.getOffset()
+        reader.read(cell, 1)
+        reader.seek(off)
+        if int(cell[0, 1]) + first_f + GAP_OPEN == self.goal_score:
+            self.found = True
+            return int(cell[0, 1])
+        return None
+
+    # -- IManager (what the aligner calls) ---------------------------------------------------------------------
+    def getRecurrenceType(self):
+        return self.recurrence
+
+    def getSpecialRowInterval(self):
+        return self.special_row_interval
+
+    def getFirstColumnInitType(self):
+        return self.first_column_reader.getType()
+
+    def getFirstRowInitType(self):
+        return self.first_row_reader.getType()
+
+    def getSuperPartition(self):
+        p = self.super_partition or self.partition
+        return Partition(p.i0 - self.seq0_offset, p.j0 - self.seq1_offset, p.i1 - self.seq0_offset, p.j1 - self.seq1_offset)
+
+    def receiveFirstRow(self, buf, length):
+        self.first_row_reader.read(buf, length)
+
+    def receiveFirstColumn(self, buf, length):
+        self.first_column_reader.read(buf, length)
+
+    def dispatchColumn(self, j, buf, length):
+        """(:334-371)"""
+        j += self.seq1_offset
+        p = self.partition
+        if j != p.j1:
+            return
+        if self.last_column_writer is not None:
+            self.last_column_writer.write(buf[:length])
+        if self.best_list is not None and self.best_location in (AT_SEQUENCE_2, AT_SEQUENCE_1_OR_2):
+            k = int(np.argmax(buf[:length, 0]))
+            self.best_list.add(p.i0 + self.last_column_pos + k, p.j1, int(buf[k, 0]))
+        if self.goal_location in (AT_ANYWHERE, AT_SEQUENCE_2, AT_SEQUENCE_1_OR_2):
+            r = self._find_goal_cell(buf, length, self.last_column_reader)
+            if r is not None:
+                self.next_crosspoint = (p.i0 + self.last_column_pos + r["k"], p.j1, r["score"],
+                                        0 if r["type"] == MATCH_ALIGNED else 1)
+                self.active = False
+        self.last_column_pos += length
+
+    def dispatchRow(self, i, buf, length):
+        """(:376-407)"""
+        i += self.seq0_offset
+        p = self.partition
+        if self.mustDispatchSpecialRows():
+            self.sra.write(i, buf[:length])
+        if i != p.i1:
+            return
+        if self.last_row_writer is not None:
+            self.last_row_writer.write(buf[:length])
+        if self.best_list is not None and self.best_location in (AT_SEQUENCE_1, AT_SEQUENCE_1_OR_2):
+            k = int(np.argmax(buf[:length, 0]))
+            self.best_list.add(p.i1, p.j0 + self.last_row_pos + k, int(buf[k, 0]))
+        if self.goal_location in (AT_ANYWHERE, AT_SEQUENCE_1, AT_SEQUENCE_1_OR_2):
+            r = self._find_goal_cell(buf, length, self.last_row_reader)
+            if r is not None:
+                self.next_crosspoint = (p.i1, p.j0 + self.last_row_pos + r["k"], r["score"],
+                                        0 if r["type"] == MATCH_ALIGNED else 2)
+                self.active = False
+        self.last_row_pos += length
+
+    def dispatchScore(self, score, bx=-1, by=-1):
+        """(:412-448): with the goal AT_ANYWHERE the alignment may START inside this partition -- the cell whose
+        reverse value is the whole goal.  No test of `found` here: a later block reporting the goal again replaces
+        an earlier hit, as in the reference."""
+        i, j, s = score
+        i += self.seq0_offset + 1
+        j += self.seq1_offset + 1
+        if s <= -INF:
+            return
+        if self.best_list is not None:
+            if self.best_location == AT_ANYWHERE:
+                self.best_list.add(i, j, s)
+            elif self.best_location == AT_SEQUENCE_1_AND_2 and i == self.partition.i1 and j == self.partition.j1:
+                self.best_list.add(i, j, s)
+        if self.goal_location == AT_ANYWHERE and s == self.goal_score:
+            self.next_crosspoint = (i, j, 0, 0)
+            self.found = True
+            self.active = False
+
+    def mustContinue(self):
+        return self.active
+
+    def mustDispatchLastCell(self):
+        return self.best_location == AT_SEQUENCE_1_AND_2
+
+    def mustDispatchLastRow(self):
+        return (self.last_row_writer is not None or self.best_location in (AT_SEQUENCE_1, AT_SEQUENCE_1_OR_2) or
+                (self.goal_location in (AT_ANYWHERE, AT_SEQUENCE_1, AT_SEQUENCE_1_OR_2) and self.last_row_reader is not None))
+
+    def mustDispatchLastColumn(self):
+        return (self.last_column_writer is not None or self.best_location in (AT_SEQUENCE_2, AT_SEQUENCE_1_OR_2) or
+                (self.goal_location in (AT_ANYWHERE, AT_SEQUENCE_2, AT_SEQUENCE_1_OR_2) and self.last_column_reader is not None))
+
+    def mustDispatchSpecialRows(self):
+        return self.sra is not None and self.sra.persistent and self.special_row_interval > 0
+
+    def mustDispatchScores(self):
+        return self.best_location == AT_ANYWHERE or self.goal_location == AT_ANYWHERE
+
+    def mustPruneBlocks(self):
+        return self.block_pruning

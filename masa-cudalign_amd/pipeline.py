@@ -1,0 +1,68 @@
+"""The whole pipeline natively: stage 1 (score + special rows), stage 2 (crosspoints on stage 1's special rows),
+stage 3 (crosspoints on the rows stages 2 and 3 save), stage 4 (Myers-Miller refinement down to 16 x 16, on the GPU:
+mi355sw_stage4), stage 5 (exact alignment of the small partitions), stage 6 (text) -- what MASA-Core's
+executeTraceback() runs after stage 1 (M/libmasa/libmasa.cpp:643-657), with the work directory in MASA-Core's layout:
+
+    <work>/crosspoints/crosspoint_01.00 .. crosspoint_04.00 (+ crosspoint_03.00.rNN per round of stage 3)
+    <work>/special_rows/stage.01.00, stage.02.00, stage.03.00.rNN
+    <work>/status, <work>/alignment.00.txt
+
+The aligner is an MI355Aligner (or anything with its setSequences / alignPartition / matchLastColumn / stage4 /
+unsetSequences); every DP cell of every stage is computed by it.  Untrimmed, unreversed sequences only: --trim and
+--reverse shift the coordinates of every stage in MASA-Core and are not carried through stages 2-3 here."""
+import os
+import time
+
+from .manager import AT_ANYWHERE
+from .engine import INF
+from .crosspoints import Crosspoint, CrosspointsFile, crosspoint_file
+from .stage1 import stage1
+from .stage2 import stage2
+from .stage3 import stage3
+from . import stage56
+
+
+def align(aligner, seq0, seq1, work, alignment_start=AT_ANYWHERE, alignment_end=AT_ANYWHERE, sra_limit=0,
+          block_pruning=True, max_partition_size=16):
+    """seq0, seq1: fasta.Sequence.  Returns {"best", "alignment": stage56.Alignment or None, "text": bytes of
+    alignment.00.txt or None when nothing scored above the floor, "crosspoints": {2: n, 3: n, 4: n},
+    "seconds": {stage: s}}"""
+    for s in (seq0, seq1):
+        if s.modifiers.reverse or s.offset0 != 1 or s.offset1 != s.original_size:
+            raise NotImplementedError("the native pipeline runs untrimmed, unreversed sequences")
+    d0, d1 = seq0.trimmed(), seq1.trimmed()
+    secs = {}
+    t = time.time()
+    r1 = stage1(aligner, d0, d1, work, alignment_start=alignment_start, alignment_end=alignment_end, sra_limit=sra_limit,
+                block_pruning=block_pruning)
+    secs[1] = time.time() - t
+    out = {"best": r1["best"], "alignment": None, "text": None, "crosspoints": {}, "seconds": secs, "stage1": r1}
+    if r1["best"] is None or r1["best"][2] <= -INF or r1["best"][0] < 0:
+        return out                                        # an empty best-score list: MASA-Core runs no traceback either
+    t = time.time()
+    r2 = stage2(aligner, d0, d1, work, alignment_start=alignment_start, sra_limit=sra_limit)
+    secs[2] = time.time() - t
+    t = time.time()
+    r3 = stage3(aligner, d0, d1, work, sra_limit=sra_limit)
+    secs[3] = time.time() - t
+    t = time.time()
+    aligner.setSequences(d0, d1)
+    try:
+        cp4, st4 = aligner.stage4(r3["crosspoints"], max_partition_size)
+    finally:
+        aligner.unsetSequences()
+    f4 = CrosspointsFile(crosspoint_file(work, 4, 0))
+    f4.extend(Crosspoint(i, j, s, ty) for (ty, i, j, s) in cp4)
+    f4.save()
+    secs[4] = time.time() - t
+    t = time.time()
+    al = stage56.stage5(seq0, seq1, cp4)
+    secs[5] = time.time() - t
+    t = time.time()
+    text = stage56.stage6_text(al, seq0, seq1)
+    with open(os.path.join(work, "alignment.00.txt"), "wb") as f:
+        f.write(text)
+    secs[6] = time.time() - t
+    out.update(alignment=al, text=text, crosspoints={2: len(r2["crosspoints"]), 3: len(r3["crosspoints"]), 4: len(cp4)},
+               stage2=r2, stage3=r3, stage4=st4)
+    return out

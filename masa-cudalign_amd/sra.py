@@ -25,9 +25,10 @@ INIT_NAMES = {INIT_WITH_ZEROES: "INIT_WITH_ZEROES", INIT_WITH_GAPS: "INIT_WITH_G
 CELL_BYTES = 8
 
 
-def special_rows_path(work, stage=1, ident=0):
+def special_rows_path(work, stage=1, ident=0, deep=-1):
     """Job::getSpecialRowsPath, M/common/Job.cpp:202-211"""
-    p = os.path.join(work, "special_rows", "stage.%02d.%02d" % (stage, ident))
+    name = "stage.%02d.%02d" % (stage, ident) if deep <= -1 else "stage.%02d.%02d.r%02d" % (stage, ident, deep)
+    p = os.path.join(work, "special_rows", name)
     os.makedirs(p, exist_ok=True)
     return p
 
@@ -62,16 +63,73 @@ class _OpenRow:
         os.replace(self.tmp, self.final)
 
 
+class SpecialRowReader:
+    """One special row opened for the traceback (SpecialRow.cpp:90-147): seeked to a cell count, it is read BACKWARDS
+    from there, every read returning its cells in reversed order -- the order in which the next stage, which sweeps
+    the reversed matrix, meets them.  Row id 0 is the partition's first row and comes from its border reader
+    (FirstRow.cpp:84-102)."""
+
+    def __init__(self, partition, rid):
+        self.partition, self.id = partition, rid
+        self.offset = 0
+
+    def getType(self):
+        return INIT_WITH_CUSTOM_DATA
+
+    def seek(self, offset):
+        self.offset = offset
+
+    def getOffset(self):
+        return self.offset
+
+    def _cells(self, offset, length):
+        if self.id == 0:
+            reader = self.partition.first_row_reader
+            tmp = np.empty((length, 2), dtype=np.int32)
+            reader.seek(offset)
+            reader.read(tmp, length)
+            return tmp
+        fn = os.path.join(self.partition.path, "%08X" % self.id)
+        a = np.fromfile(fn, dtype=np.int32, count=2 * length, offset=CELL_BYTES * offset).reshape(-1, 2)
+        if a.shape[0] != length:
+            raise RuntimeError("end of special row %s: %d cells at %d, file ends after %d" % (fn, length, offset, a.shape[0]))
+        return a
+
+    def read(self, buf, length):
+        if self.offset == 0:
+            raise RuntimeError("special row overflow: %d cells asked from row %08X at its start" % (length, self.id))
+        length = min(length, self.offset)
+        self.offset -= length
+        if buf is not None:
+            buf[:length] = self._cells(self.offset, length)[::-1]
+        return length
+
+
 class SpecialRowsPartition:
     """One partition directory of the area (SpecialRowsPartition.cpp).  Coordinates as in the reference: rows i0..i1,
-    columns j0..j1 of the DP matrix, row i0 / column j0 being the border."""
+    columns j0..j1 of the DP matrix, row i0 / column j0 being the border.  `persistent=False` is the reference's
+    partition without a path (SpecialRowsArea::getPartitionPath returns "" for non-persistent areas): it takes the
+    border readers and drops every row."""
 
-    def __init__(self, area_path, i0, j0, i1, j1):
+    def __init__(self, area_path, i0, j0, i1, j1, read_only=False, persistent=True):
         self.i0, self.j0, self.i1, self.j1 = i0, j0, i1, j1
-        self.path = os.path.join(area_path, "%08X.%08X.%08X.%08X" % (i0, j0, i1, j1))
-        os.makedirs(self.path, exist_ok=True)
+        self.read_only, self.persistent = read_only, persistent
+        self.first_row_reader = self.first_column_reader = None
+        self.last_row_writer = self.last_column_writer = None
         self._open = {}
-        self.rows = []                 # ids (i - i0) of complete rows, ascending
+        self.rows = []                 # ids (i - i0) of complete rows, ascending (the first row, id 0, is implicit)
+        self.reading = None            # SpecialRowReader handed out last
+        self._reading_idx = 0
+        self.largest_interval = 0
+        if not persistent:
+            self.path = ""
+            return
+        self.path = os.path.join(area_path, "%08X.%08X.%08X.%08X" % (i0, j0, i1, j1))
+        if read_only:
+            if not os.path.isdir(self.path):
+                raise RuntimeError("special rows partition %s does not exist" % self.path)
+        else:
+            os.makedirs(self.path, exist_ok=True)
         self.read_directory()
 
     # -- directory ---------------------------------------------------------------------------------------------
@@ -84,7 +142,109 @@ class SpecialRowsPartition:
                 os.remove(os.path.join(self.path, fn))
             elif len(fn) == 8 and all(c in "0123456789ABCDEF" for c in fn):
                 rows.append(int(fn, 16))
+            elif fn[:1] in ("C", "R") and len(fn) > 10 and fn[9] == ".":
+                self._load_border_reader(fn)
         self.rows = sorted(rows)
+        self.reload()
+
+    def _load_border_reader(self, fn):
+        """loadBorderReader (:490-515): how a border was made is in the marker's name"""
+        from .manager import InitialCellsReader, FileCellsReader, GAP_OPEN, GAP_EXT
+        offset, typ = int(fn[1:9], 16), fn[10:]
+        if typ == "INIT_WITH_CUSTOM_DATA":
+            reader = FileCellsReader(os.path.join(self.path, fn))
+        elif typ == "INIT_WITH_ZEROES":
+            reader = InitialCellsReader(start_offset=offset)
+        elif typ == "INIT_WITH_GAPS":
+            reader = InitialCellsReader(GAP_OPEN + offset * GAP_EXT, GAP_EXT)
+        elif typ == "INIT_WITH_GAPS_OPENED":
+            reader = InitialCellsReader(offset * GAP_EXT, GAP_EXT)
+        else:
+            return
+        if fn[0] == "C":
+            self.first_column_reader = reader
+        else:
+            self.first_row_reader = reader
+
+    def reload(self):
+        """(:177-184): the traceback reads the rows from the last one upwards"""
+        self.rows.sort()
+        self._reading_idx = len(self.rows)          # index into [first row] + rows
+        self.reading = None
+        ids = [0] + self.rows
+        self.largest_interval = max([b - a for a, b in zip(ids, ids[1:])] or [0])
+
+    def rows_count(self):
+        """getRowsCount (:272-274): the first row counts"""
+        return len(self.rows) + 1
+
+    def get_reading_row(self):
+        """(:198-200) absolute DP row of the special row handed out last"""
+        return self.i0 + self.reading.id
+
+    def next_special_row(self, i, j, min_dist):
+        """nextSpecialRow (:383-429): the nearest row more than `min_dist` rows above DP row i (the first row when none
+        is), opened and seeked so that its first read starts at column j and walks towards j0.  None when (i, j)
+        already sits on the first row."""
+        ids = [0] + self.rows
+        while self._reading_idx >= 0:
+            dist = (i - self.i0) - ids[self._reading_idx]
+            if self._reading_idx == 0:
+                if dist > 0:
+                    break
+                return None
+            if dist > min_dist:
+                break
+            self._reading_idx -= 1
+        self.reading = SpecialRowReader(self, ids[self._reading_idx])
+        self.reading.seek(abs(j - self.j0) + 1)
+        return self.reading
+
+    # -- border readers as the stage that creates the partition sets them (:111-175) ---------------------------
+    def set_first_row_reader(self, reader):
+        self.first_row_reader = reader
+        self._border_marker("R", reader)
+
+    def set_first_column_reader(self, reader):
+        self.first_column_reader = reader
+        self._border_marker("C", reader)
+
+    def _border_marker(self, prefix, reader):
+        if reader is None or not self.persistent:
+            return
+        typ = reader.getType()
+        if typ == INIT_WITH_CUSTOM_DATA:
+            raise NotImplementedError("custom-data borders of a traceback partition (TeeCellsReader) are not used by "
+                                      "stages 2-3 and not built")
+        open(os.path.join(self.path, "%s%08X.%s" % (prefix, reader.getStartOffset(), INIT_NAMES[typ])), "wb").close()
+
+    # -- truncation once the crosspoint is known (:202-236) ----------------------------------------------------
+    def truncate(self, max_i, max_j):
+        """rows at or below DP row max_i go away, the others keep columns j0..max_j"""
+        if self.persistent:
+            for rid, row in list(self._open.items()):
+                row.f.close()
+                os.replace(row.tmp, row.final)      # SpecialRowFile::close renames whatever was written
+                if rid not in self.rows:
+                    self.rows.append(rid)
+            self._open = {}
+            keep, cells = [], max_j - self.j0 + 1
+            for rid in sorted(self.rows):
+                fn = os.path.join(self.path, "%08X" % rid)
+                if rid + self.i0 >= max_i:
+                    os.remove(fn)
+                else:
+                    if cells * CELL_BYTES < os.path.getsize(fn):
+                        os.truncate(fn, cells * CELL_BYTES)
+                    keep.append(rid)
+            self.rows = keep
+        self.i1, self.j1 = max_i, max_j
+        self.reload()
+
+    def change_path(self, new_path):
+        if self.persistent:
+            os.rename(self.path, new_path)
+            self.path = new_path
 
     @property
     def width_cells(self):
@@ -110,6 +270,10 @@ class SpecialRowsPartition:
     # -- writing (write, :335-353) -----------------------------------------------------------------------------
     def write(self, i, cells):
         """append cells to row i; returns True when the row became complete (closed + renamed)"""
+        if self.read_only:
+            raise RuntimeError("writing into a read-only special rows partition")
+        if not self.persistent:
+            return False
         rid = i - self.i0
         row = self._open.get(rid)
         if row is None:
@@ -135,6 +299,69 @@ class SpecialRowsPartition:
         partition; the caller advances its first-column reader by (row - i0) cells"""
         i = self.last_row_id()
         return i, self.read_row(i)
+
+
+class SpecialRowsArea:
+    """M/common/sra/SpecialRowsArea.cpp: the partitions of one stage (one directory)"""
+
+    def __init__(self, directory, persistent=True):
+        self.directory = directory
+        self.persistent = persistent
+        self.partitions = {}
+        self._anonymous = []           # non-persistent partitions have no path to be keyed by
+        self.rows = 0
+
+    def set_persistent(self, persistent):
+        self.persistent = persistent
+
+    def create_partition(self, i0, j0, i1, j1):
+        p = SpecialRowsPartition(self.directory, i0, j0, i1, j1, persistent=self.persistent)
+        if self.persistent:
+            self.partitions[p.path] = p
+        else:
+            self.partitions[""] = p    # createPartition keys by path: every non-persistent partition lands on ""
+        return p
+
+    def open_partition(self, i0, j0, i1, j1):
+        """openPartition(i0,j0,i1,j1) (:66-78)"""
+        path = os.path.join(self.directory, "%08X.%08X.%08X.%08X" % (i0, j0, i1, j1))
+        p = self.partitions.get(path)
+        if p is None:
+            p = self.partitions[path] = SpecialRowsPartition(self.directory, i0, j0, i1, j1, read_only=True)
+        else:
+            p.reload()
+        return p
+
+    def open_partition_at(self, i, j):
+        """openPartition(i, j) (:118-146): the partition whose cells (border excluded) hold DP cell (i, j)"""
+        for name in os.listdir(self.directory):
+            tok = name.split(".")
+            if len(tok) == 4 and all(len(t) == 8 for t in tok):
+                try:
+                    i0, j0, i1, j1 = (int(t, 16) for t in tok)
+                except ValueError:
+                    continue
+                if i0 < i <= i1 and j0 < j <= j1:
+                    return self.open_partition(i0, j0, i1, j1)
+        return None
+
+    def truncate_partition(self, p, max_i, max_j):
+        """(:80-95)"""
+        old = p.path
+        p.truncate(max_i, max_j)
+        if self.persistent:
+            new = os.path.join(self.directory, "%08X.%08X.%08X.%08X" % (p.i0, p.j0, max_i, max_j))
+            p.change_path(new)
+            self.partitions.pop(old, None)
+            self.partitions[new] = p
+        self.rows += p.rows_count()
+
+    def rows_count(self):
+        """(:97-103)"""
+        return self.rows if self.persistent else 0
+
+    def partitions_count(self):
+        return len(self.partitions)
 
 
 class Status:
@@ -178,6 +405,23 @@ class Status:
         with open(self.tmp, "w") as f:
             f.write("%d\n%d\n%d %d %d\n" % (self.stage, self.last_special_row, b[0], b[1], b[2]))
         os.replace(self.tmp, self.file)
+
+
+def flush_intervals(m, n, limit, max_deep=20):
+    """Job::calculateFlushIntervals, M/common/Job.cpp:231-257: the special-row spacing of stage 1, stage 2 and the
+    rounds of stage 3.  From the second entry on the reference divides by `limit / SRA_DECAY` with SRA_DECAY = 1.0f:
+    single-precision arithmetic, reproduced here."""
+    if limit < n * CELL_BYTES * 2:
+        limit = n * CELL_BYTES * 2
+    f32 = np.float32
+    out = [int(m * n * CELL_BYTES // limit + 1)]
+    for k in range(1, max_deep):
+        length = n if k % 2 == 1 else m
+        v = int(f32(out[k - 1] * length * CELL_BYTES) / f32(limit) + f32(1))
+        if k >= 2 and v > out[k - 2] // 2:
+            v = out[k - 2] // 2                      # each round at least halves the spacing of the round before last
+        out.append(v)
+    return out
 
 
 def flush_interval(m, n, limit):

@@ -101,7 +101,9 @@ def stage1(aligner, seq0, seq1, work, alignment_start=AT_ANYWHERE, alignment_end
     if part_sra is not None:
         status.last_special_row = part_sra.last_row_id()
     status.save(best)
-    sra_mod.write_crosspoint(sra_mod.crosspoint_path(work, 1, 0), best)
+    if best[0] >= 0 and best[2] > -sra_mod.INF:
+        sra_mod.write_crosspoint(sra_mod.crosspoint_path(work, 1, 0), best)
+    # else: an empty best-score list -- MASA-Core writes no crosspoint file and runs no traceback (sw_stage1.cpp:481-492: one file per entry of the list)
     st = aligner.getStatistics()
     return {"best": tuple(best), "resumed_from": resumed_from, "seconds": dt,
             "gcups": float(m - i0) * n / dt / 1e9 if dt > 0 else 0.0, "strip_rows": st["strip_rows"],

@@ -1,0 +1,296 @@
+"""CPU: the native traceback drivers (masa-cudalign_amd/stage2.py, stage3.py, pipeline.py, the AlignerManager of
+manager.py, the read side of sra.py, crosspoints.py) against MASA-Core.
+
+The drivers never compute a DP cell themselves: they talk to an aligner.  Here the aligner is
+oracle/aligner_double.py -- MASA-Core's serial block aligner restated over the oracle's processBlock, the very aligner
+oracle/ref_driver.cpp linked into the real MASA-Core when the fixtures were made.  Same grid, same special rows, same
+order of dispatches: so the native drivers must reproduce the reference's crosspoint files of stages 2, 3 (every
+round) and 4, its special-rows directories of stages 2 and 3, and alignment.00.txt, BYTE FOR BYTE -- against the
+committed fixtures, and against the live reference (where oracle/_ref is built) on inputs chosen to reach gapped
+crosspoints, both gap types, several rounds of stage 3, local / global / semi-global edges and the alignment's start
+inside a partition.  On the GPU the same drivers run on the engine: tests/test_gpu_native_pipeline.py."""
+import filecmp
+import hashlib
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from helpers import load_golden, make_pair
+
+G = load_golden()
+FULL = [c for c in G["cases"] if "crosspoints_4" in c]
+
+
+def _double(oracle, case_args):
+    from oracle.aligner_double import SerialBlockAligner
+    bh, bw = [a for a in case_args if a.startswith("--block=")][0][8:].split(",")
+    return SerialBlockAligner(int(bh), int(bw))
+
+
+def _limit(case_args):
+    v = [a for a in case_args if a.startswith("--disk-size=")][0][12:]
+    mult = {"K": 1024, "M": 1024 * 1024, "G": 1024 ** 3}.get(v[-1])
+    return int(float(v[:-1]) * mult) if mult else int(v)
+
+
+def _fasta(pkg, s0, s1):
+    from masa_cudalign_amd import fasta
+    return fasta.parse(b">s0\n" + s0.tobytes() + b"\n"), fasta.parse(b">s1\n" + s1.tobytes() + b"\n")
+
+
+@pytest.mark.parametrize("case", FULL, ids=[c["name"] for c in FULL])
+def test_pipeline_reproduces_the_fixture(case, pkg, oracle, tmp_path):
+    """stages 1-6 natively on the fixture's pair with the fixture's block geometry: crosspoints of stages 2 and 3 equal
+    the reference's lists, crosspoint_04.00 and alignment.00.txt its files (sha256).  The pruned fixture's reference
+    run pruned 143 blocks in stage 1; the double does not prune -- the crosspoints do not depend on it."""
+    from masa_cudalign_amd import pipeline
+    from masa_cudalign_amd.crosspoints import CrosspointsFile, crosspoint_file
+    s0, s1 = make_pair(pkg, case["seq"])
+    q0, q1 = _fasta(pkg, s0, s1)
+    work = str(tmp_path / "work")
+    out = pipeline.align(_double(oracle, case["args"]), q0, q1, work, sra_limit=_limit(case["args"]), block_pruning=False)
+    assert list(out["best"]) == case["best"]
+    cp2 = CrosspointsFile(crosspoint_file(work, 2)).load().tuples()
+    cp3 = CrosspointsFile(crosspoint_file(work, 3)).load().tuples()
+    assert cp2 == [tuple(p) for p in case["crosspoints_2"]]
+    assert cp3 == [tuple(p) for p in case["crosspoints_3"]]
+    assert hashlib.sha256(open(crosspoint_file(work, 4), "rb").read()).hexdigest() == case["crosspoints_4"]["file_sha256"]
+    assert hashlib.sha256(out["text"]).hexdigest() == case["alignment_txt_sha256"]
+    assert open(os.path.join(work, "alignment.00.txt"), "rb").read() == out["text"]
+    assert out["alignment"].raw_score == case["best"][2]
+
+
+def _gap_rich():
+    rng = np.random.default_rng(9)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    a = rng.choice(acgt, size=6000)
+    s0 = np.concatenate([rng.choice(acgt, size=300), a[:2000], rng.choice(acgt, size=700), a[2000:], rng.choice(acgt, size=200)])
+    s1 = np.concatenate([a[:4500], rng.choice(acgt, size=450), a[4500:]])
+    return s0, s1
+
+
+def _contained(pkg):
+    a = pkg.seqgen.random_dna(777, 4000)
+    s0 = np.concatenate([pkg.seqgen.random_dna(778, 2500), a, pkg.seqgen.random_dna(779, 1500)])
+    return s0, pkg.seqgen.mutate_dna(a, 780, inversion=0.0)
+
+
+LIVE = [
+    # name, pair, block h, block w, area limit, edges
+    ("gap_rich_types_0_1", lambda pkg: _gap_rich(), 128, 128, 100 * 1024, "**"),
+    ("gap_rich_other_grid", lambda pkg: _gap_rich(), 300, 200, 60 * 1024, "**"),
+    ("unrelated_start_inside_first_partition", lambda pkg: pkg.seqgen.unrelated_pair(5000, 5000, cfg=3), 128, 128, 100 * 1024, "**"),
+    ("many_indels", lambda pkg: pkg.seqgen.related_pair(12000, 12000, cfg=21, p_indel=0.02, indel_mean=6.0), 128, 128, 300 * 1024, "**"),
+    ("wide_long_indels", lambda pkg: pkg.seqgen.related_pair(9000, 14000, cfg=22, p_indel=0.01, indel_mean=20.0), 256, 128, 200 * 1024, "**"),
+    ("two_rounds_of_stage3", lambda pkg: pkg.seqgen.related_pair(27648, 27648, cfg=7), 256, 256, 663552, "**"),
+    ("global", lambda pkg: pkg.seqgen.related_pair(6000, 6100, cfg=23, inversion=0.0), 128, 128, 150 * 1024, "++"),
+    ("contained_global_all_types", _contained, 128, 128, 150 * 1024, "++"),
+    ("contained_semiglobal_21", _contained, 128, 128, 150 * 1024, "21"),
+    ("contained_semiglobal_31", _contained, 128, 128, 150 * 1024, "31"),
+    ("contained_start_on_s2", _contained, 128, 128, 150 * 1024, "2*"),
+    ("contained_swapped_12", lambda pkg: _contained(pkg)[::-1], 128, 256, 150 * 1024, "12"),
+    ("contained_swapped_global", lambda pkg: _contained(pkg)[::-1], 128, 256, 150 * 1024, "22"),
+    ("no_traceback_13", _contained, 128, 128, 150 * 1024, "13"),
+]
+
+
+@pytest.mark.parametrize("name,pair,bh,bw,limit,edges", LIVE, ids=[x[0] for x in LIVE])
+def test_stages_1_to_3_against_the_live_reference(name, pair, bh, bw, limit, edges, pkg, oracle, tmp_path):
+    """every crosspoint file (02, 03.rNN, 03) and every special-rows directory of stages 2-3 equals MASA-Core's"""
+    if not oracle.have_ref():
+        pytest.skip("oracle/_ref not built (needs /root/reference)")
+    from oracle.aligner_double import SerialBlockAligner
+    from masa_cudalign_amd.stage1 import stage1
+    from masa_cudalign_amd.stage2 import stage2
+    from masa_cudalign_amd.stage3 import stage3
+    edge = {"*": pkg.AT_ANYWHERE, "1": pkg.AT_SEQUENCE_1, "2": pkg.AT_SEQUENCE_2, "3": pkg.AT_SEQUENCE_1_OR_2,
+            "+": pkg.AT_SEQUENCE_1_AND_2}
+    s0, s1 = pair(pkg)
+    m = len(s0)
+    args = ["--disk-size=%d" % limit, "--block=%d,%d" % (bh, bw), "--no-block-pruning"]
+    if edges != "**":
+        args.append("--edges=" + edges)
+    refdir = tmp_path / "ref"
+    refdir.mkdir()
+    ref = oracle.run_ref(s0, s1, args, workdir=str(refdir), timeout=600)
+    rwork = str(refdir / "work")
+    work = str(tmp_path / "native")
+    al = SerialBlockAligner(bh, bw)
+    r1 = stage1(al, s0, s1, work, alignment_start=edge[edges[0]], alignment_end=edge[edges[1]], sra_limit=limit,
+                block_pruning=False)
+    assert tuple(r1["best"]) == tuple(ref["best"])
+    r2 = stage2(al, s0, s1, work, alignment_start=edge[edges[0]], sra_limit=limit)
+    r3 = stage3(al, s0, s1, work, sra_limit=limit)
+    files = sorted(f for f in os.listdir(os.path.join(rwork, "crosspoints")) if not f.startswith("crosspoint_04"))
+    assert "crosspoint_02.00" in files and "crosspoint_03.00" in files
+    for f in files:
+        assert filecmp.cmp(os.path.join(rwork, "crosspoints", f), os.path.join(work, "crosspoints", f), shallow=False), f
+    for d in sorted(os.listdir(os.path.join(rwork, "special_rows"))):
+        # (the native stage 1 also keeps the partition's last row as its completion marker: manager.py)
+        p = subprocess.run(["diff", "-rq", "-x", "%08X" % m, os.path.join(rwork, "special_rows", d),
+                            os.path.join(work, "special_rows", d)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+        assert p.returncode == 0, p.stdout.decode()[:2000]
+    if name == "two_rounds_of_stage3":
+        assert len(r3["rounds"]) == 2 and "crosspoint_03.00.r02" in files
+    if name.startswith("contained_global"):
+        assert {t for (t, _, _, _) in r3["crosspoints"] + r2["crosspoints"]} == {0, 1, 2}
+    if name.startswith("no_traceback"):
+        assert len(r2["crosspoints"]) == 1 and r2["partitions"] == 0
+
+
+def test_nothing_to_trace_back(pkg, oracle, tmp_path):
+    """a global start with a local end and nothing above the floor: MASA-Core's best-score list stays empty, it writes
+    no crosspoint file and runs no traceback; neither does the native pipeline"""
+    from masa_cudalign_amd import pipeline
+    from oracle.aligner_double import SerialBlockAligner
+    s0, s1 = _contained(pkg)
+    q0, q1 = _fasta(pkg, s0, s1)
+    work = str(tmp_path / "work")
+    out = pipeline.align(SerialBlockAligner(128, 128), q0, q1, work, alignment_start=pkg.AT_SEQUENCE_1_AND_2,
+                         alignment_end=pkg.AT_ANYWHERE, sra_limit=150 * 1024, block_pruning=False)
+    assert out["text"] is None and out["alignment"] is None
+    assert not os.path.exists(os.path.join(work, "crosspoints", "crosspoint_01.00"))
+
+
+def test_flush_intervals_follow_the_reference_arithmetic(pkg):
+    """Job::calculateFlushIntervals: integer arithmetic for stage 1, single precision from stage 2 on, every round at
+    most half of the round before last.  317 / 34 are what MASA-Core printed for the 3000 x 2700 fixture
+    (statistics_02.00: "Flush Interval: 34"), 6868 / 786 for 60000 x 50000 with 4 MiB."""
+    from masa_cudalign_amd import sra
+    assert sra.flush_intervals(3000, 2700, 200 * 1024)[:4] == [317, 34, 4, 1]
+    assert sra.flush_interval(3000, 2700, 200 * 1024) == 317
+    f = sra.flush_intervals(40000, 30000, 1024)          # limit below two rows: raised to two rows
+    assert f[:3] == [20001, 10001, 6668] and all(b <= a for a, b in zip(f, f[1:]))
+    f = sra.flush_intervals(27648, 27648, 663552)
+    assert f[0] == 9217 and f[1] >= 1024 > f[3]
+    # 48 M x 46 M with 25 GB (BASELINE C3): single precision decides the last digits
+    f = sra.flush_intervals(48000000, 46000000, 25 * 1000 ** 3)
+    assert f[0] == 48000000 * 46000000 * 8 // (25 * 1000 ** 3) + 1
+    assert f[1] == int(np.float32(f[0] * 46000000 * 8) / np.float32(25 * 1000 ** 3) + np.float32(1))
+
+
+def test_crosspoints_file_and_reversal(pkg, tmp_path):
+    from masa_cudalign_amd.crosspoints import Crosspoint, CrosspointsFile, TYPE_GAP_1, TYPE_GAP_2
+    c = Crosspoint(10, 20, 7, TYPE_GAP_1)
+    r = c.reverse(100, 200)
+    assert r.astuple() == (TYPE_GAP_2, 180, 90, 7) and r.reverse(200, 100) == c
+    fn = str(tmp_path / "crosspoints" / "crosspoint_02.00")
+    f = CrosspointsFile(fn).open()
+    f.write(Crosspoint(0, 0, 0, 0))
+    assert os.path.exists(fn + ".tmp") and not os.path.exists(fn)          # visible under its name only once closed
+    f.write(c)
+    f.close()
+    assert open(fn).read() == "START\n0,0,0,0\n1,10,20,7\nEND\n"
+    g = CrosspointsFile(fn).load()
+    assert g.tuples() == [(0, 0, 0, 0), (1, 10, 20, 7)]
+    g.reverse_all(100, 200)
+    assert g.tuples() == [(2, 180, 90, 7), (0, 200, 100, 0)]
+    g.save()
+    assert CrosspointsFile(fn).load().tuples() == g.tuples()
+    assert CrosspointsFile(str(tmp_path / "missing")).load() == []
+
+
+def test_special_rows_are_read_backwards(pkg, tmp_path):
+    """a row written left to right by one stage is read right to left by the next: seek(j - j0 + 1), then every read
+    hands over the cells in reversed order; row 0 is the partition's first row, made from its border marker"""
+    from masa_cudalign_amd import sra
+    from masa_cudalign_amd.manager import InitialCellsReader, ReversedCellsReader
+    area = sra.SpecialRowsArea(str(tmp_path))
+    p = area.create_partition(100, 50, 400, 60)
+    p.set_first_row_reader(InitialCellsReader(3, 2))
+    p.set_first_column_reader(InitialCellsReader(0, 2))
+    cells = np.arange(22, dtype=np.int32).reshape(11, 2)
+    for i in (228, 356):
+        assert p.write(i, cells[:4] + i) is False
+        assert p.write(i, cells[4:] + i) is True
+    assert sorted(os.listdir(p.path)) == ["00000080", "00000100", "C00000000.INIT_WITH_GAPS_OPENED", "R00000000.INIT_WITH_GAPS"]
+    q = sra.SpecialRowsArea(str(tmp_path)).open_partition_at(101, 51)
+    assert (q.i0, q.j0, q.i1, q.j1) == (100, 50, 400, 60) and q.rows_count() == 3 and q.largest_interval == 128
+    assert q.first_row_reader.getType() == pkg.INIT_WITH_GAPS and q.first_column_reader.getType() == pkg.INIT_WITH_GAPS_OPENED
+    # from DP cell (390, 57): row 356 is closer than 128 rows and skipped; row 228 is the one
+    r = q.next_special_row(390, 57, 128)
+    assert q.get_reading_row() == 228 and r.getOffset() == 8
+    buf = np.empty((3, 2), dtype=np.int32)
+    assert r.read(buf, 3) == 3 and np.array_equal(buf, (cells[5:8] + 228)[::-1])
+    buf = np.empty((9, 2), dtype=np.int32)
+    assert r.read(buf, 9) == 5 and np.array_equal(buf[:5], (cells[:5] + 228)[::-1])      # clamped at the row's start
+    with pytest.raises(RuntimeError):
+        r.read(buf, 1)
+    # from (229, 55): only the first row is left, -2k-3 with the corner 0
+    r = q.next_special_row(229, 55, 128)
+    assert q.get_reading_row() == 100
+    buf = np.empty((6, 2), dtype=np.int32)
+    assert r.read(buf, 6) == 6 and list(buf[:, 0]) == [-13, -11, -9, -7, -5, 0]
+    assert q.next_special_row(100, 55, 128) is None
+    # truncation at a crosspoint: rows at or below it go, the others are cut to its column
+    area.truncate_partition(p, 300, 55)
+    assert os.path.basename(p.path) == "00000064.00000032.0000012C.00000037"
+    assert sorted(f for f in os.listdir(p.path) if len(f) == 8) == ["00000080"]
+    assert os.path.getsize(os.path.join(p.path, "00000080")) == 6 * 8
+    assert area.rows_count() == 2 and area.partitions_count() == 1
+    # a border read backwards
+    col = ReversedCellsReader(InitialCellsReader(3, 2))
+    col.seek(4)
+    buf = np.empty((4, 2), dtype=np.int32)
+    assert col.read(buf, 10) == 4 and list(buf[:, 0]) == [-9, -7, -5, 0]
+    # a non-persistent area swallows rows and counts nothing
+    vol = sra.SpecialRowsArea(str(tmp_path / "none"), persistent=False)
+    vp = vol.create_partition(0, 0, 10, 10)
+    vp.set_first_row_reader(InitialCellsReader(3, 2))
+    assert vp.write(5, cells) is False and vol.rows_count() == 0 and not os.path.exists(str(tmp_path / "none"))
+
+
+def test_manager_goal_matching(pkg, oracle):
+    """AlignerManager: the full-gap shortcut before the sweep, the first matching cell of a dispatched column, the error
+    on a border sum above the goal, and the start of a local alignment reported through the block scores"""
+    from oracle.aligner_double import SerialBlockAligner
+    from masa_cudalign_amd.manager import (AlignerManager, ArrayCellsReader, InitialCellsReader, BacktraceLost,
+                                           START_TYPE_MATCH, START_TYPE_GAP_H)
+    INF = pkg.INF
+    al = SerialBlockAligner(64, 64)
+    mg = AlignerManager(al)
+
+    class Part:                                          # what a stage hands over per partition: fresh border streams
+        persistent, last_column_writer, last_row_writer = False, None, None
+
+        def __init__(self):
+            self.first_row_reader, self.first_column_reader = InitialCellsReader(3, 2), InitialCellsReader(3, 2)
+    mg.setSpecialRowsPartition(Part())
+    mg.setRecurrenceType(pkg.NEEDLEMAN_WUNSCH)
+    # full gap: the forward F of the border cell + a run of 5 columns (opened: the start type is not a gap along S1)
+    base = np.array([[50, 40]], dtype=np.int32)
+    mg.setGoalScore(40 - 5 * 2 - 3 + 3, pkg.AT_SEQUENCE_1_OR_2)
+    mg.setLastColumnReader(ArrayCellsReader(base))
+    mg.setLastRowReader(None)
+    mg.alignPartition(pkg.Partition(0, 0, 7, 5), START_TYPE_MATCH)
+    assert mg.isFoundCrosspoint() and mg.getNextCrosspoint() == (0, 5, 40, 1) and al.partitions == 0
+    # the same border with the gap already open on arrival
+    mg.setGoalScore(40 - 5 * 2 + 3, pkg.AT_SEQUENCE_1_OR_2)
+    mg.alignPartition(pkg.Partition(0, 0, 7, 5), START_TYPE_GAP_H)
+    assert mg.isFoundCrosspoint() and al.partitions == 0
+    # a real sweep: identical sequences, goal met on the last column where forward + reverse add up
+    s = pkg.seqgen.random_dna(5, 40)
+    mg.setSequences(s, s, 0, 0, 40, 40)
+    fwd = np.zeros((41, 2), dtype=np.int32)
+    fwd[:, 0] = 100 - np.arange(41)                      # forward H along the matched border
+    fwd[:, 1] = -INF
+    mg.setGoalScore(100 - 30 + 30, pkg.AT_SEQUENCE_1_OR_2)          # reverse H on the diagonal is +30 at row 30
+    mg.setSpecialRowsPartition(Part())
+    mg.setLastColumnReader(ArrayCellsReader(fwd))
+    mg.alignPartition(pkg.Partition(0, 0, 40, 30), START_TYPE_MATCH)
+    assert mg.isFoundCrosspoint() and mg.getNextCrosspoint() == (30, 30, 70, 0) and not mg.mustContinue()
+    # a border that promises more than the goal: the reference exits with "Backtrace lost"
+    mg.setGoalScore(20, pkg.AT_SEQUENCE_1_OR_2)
+    mg.setSpecialRowsPartition(Part())
+    mg.setLastColumnReader(ArrayCellsReader(fwd))
+    with pytest.raises(BacktraceLost):
+        mg.alignPartition(pkg.Partition(0, 0, 40, 30), START_TYPE_MATCH)
+    # local start: no border to match, the block whose best reverse value is the whole goal
+    mg.setGoalScore(40, pkg.AT_ANYWHERE)
+    mg.setSpecialRowsPartition(Part())
+    mg.setLastColumnReader(None)
+    mg.alignPartition(pkg.Partition(0, 0, 40, 40), START_TYPE_MATCH)
+    assert mg.isFoundCrosspoint() and mg.getNextCrosspoint() == (40, 40, 0, 0)
+    mg.unsetSequences()
