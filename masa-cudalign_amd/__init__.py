@@ -17,3 +17,7 @@ from .manager import (  # noqa: F401
 from . import seqgen  # noqa: F401
 from . import sra  # noqa: F401
 from .stage1 import stage1  # noqa: F401
+from .manager import AlignerManager, BacktraceLost  # noqa: F401
+from .stage2 import stage2  # noqa: F401
+from .stage3 import stage3  # noqa: F401
+from . import crosspoints, pipeline  # noqa: F401

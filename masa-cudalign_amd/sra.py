@@ -223,6 +223,9 @@ class SpecialRowsPartition:
         """rows at or below DP row max_i go away, the others keep columns j0..max_j"""
         if self.persistent:
             for rid, row in list(self._open.items()):
+                if rid + self.i0 < max_i and row.offset < max_j - self.j0 + 1:
+                    raise RuntimeError("special row %08X of %s kept by the crosspoint (%d,%d) holds %d of %d cells"
+                                       % (rid, self.path, max_i, max_j, row.offset, max_j - self.j0 + 1))
                 row.f.close()
                 os.replace(row.tmp, row.final)      # SpecialRowFile::close renames whatever was written
                 if rid not in self.rows:

@@ -1,0 +1,61 @@
+"""The whole pipeline natively on one MI355X (masa-cudalign_amd/pipeline.py: stages 1-3 drive the engine, stage 4 is
+mi355sw_stage4, stages 5-6 host code), timed per stage -- the counterpart of tools/dropin_scale.py, which runs
+MASA-Core's own stages on top of the engine.
+
+    python tools/native_pipeline_run.py M N [sra_bytes] [out.json] [cfg]
+
+Related pair from seqgen (cfg as in BASELINE.md section 2), local alignment, block pruning on.  Checks: the text
+re-scores itself to the best score (stage 5 refuses anything else), and -- for sizes the oracle finishes in seconds --
+the best score equals the oracle's.  `MI355SW_WORK` overrides the work directory (default: a temporary one, removed)."""
+import json
+import os
+import shutil
+import sys
+import tempfile
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import __graft_entry__ as g  # noqa: E402
+
+pkg = g.load_package()
+from masa_cudalign_amd import fasta, pipeline  # noqa: E402
+
+
+def main():
+    m, n = int(sys.argv[1]), int(sys.argv[2])
+    limit = int(float(sys.argv[3])) if len(sys.argv) > 3 else max(200 * 1024, (m // 8192 + 1) * n * 8)
+    outfn = sys.argv[4] if len(sys.argv) > 4 else None
+    cfg = int(sys.argv[5]) if len(sys.argv) > 5 else 2
+    s0, s1 = pkg.seqgen.related_pair(m, n, cfg=cfg)
+    q0 = fasta.Sequence(">s0", s0, fasta.SequenceModifiers())
+    q1 = fasta.Sequence(">s1", s1, fasta.SequenceModifiers())
+    work = os.environ.get("MI355SW_WORK") or tempfile.mkdtemp(prefix="mi355_native_")
+    al = pkg.MI355Aligner(device=0)
+    t0 = time.time()
+    try:
+        out = pipeline.align(al, q0, q1, work, sra_limit=limit)
+    finally:
+        al.close()
+    total = time.time() - t0
+    res = {"workload": "%dx%d related pair (seqgen cfg=%d), local, stages 1-6 natively" % (m, n, cfg), "sra_bytes": limit,
+           "best": list(out["best"]), "seconds": {str(k): v for k, v in out["seconds"].items()}, "total_seconds": total,
+           "crosspoints": {str(k): v for k, v in out["crosspoints"].items()},
+           "stage1_gcups": out["stage1"]["gcups"], "stage3_rounds": out.get("stage3", {}).get("rounds"),
+           "stage4": out.get("stage4"), "alignment_score": out["alignment"].raw_score if out["alignment"] else None,
+           "text_bytes": len(out["text"]) if out["text"] else 0}
+    if float(m) * n <= 4e9:
+        oracle = g.load_oracle()
+        res["oracle_best"] = list(oracle.stage1(s0, s1)["best"])
+        res["ok"] = res["oracle_best"][2] == res["best"][2] == res["alignment_score"]
+    else:
+        res["ok"] = res["best"][2] == res["alignment_score"]
+    print(json.dumps(res), flush=True)
+    if outfn:
+        json.dump(res, open(outfn, "w"), indent=1)
+    if not os.environ.get("MI355SW_WORK"):
+        shutil.rmtree(work, ignore_errors=True)
+    assert res["ok"], res
+
+
+if __name__ == "__main__":
+    main()
