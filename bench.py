@@ -13,7 +13,11 @@ sequences already resident in HBM.
           bands; the boundary column goes GPU to GPU through column ports (bands.py transport "p2p": band g's strip
           kernel stores its last column into band g+1's HBM over xGMI and publishes the row count, band g+1's kernel
           polls it); barrier, best-score all_gather and timing all_reduce go over RCCL, the 80-byte port handles
-          over a gloo side group.  MI355SW_BENCH_COMM=host selects the pinned-host + gloo transport instead.
+          over a gloo side group.  Before anything is timed the ranks check the ports: every rank maps its neighbour's
+          (bands.probe_p2p), then a 1 Mi-row chain runs once through the ports and once through the host and every
+          band compares the column it received and the best cell it found (bands.verify_p2p, a minute's budget); if
+          any rank fails either, ALL ranks use the pinned-host + gloo transport and the line says so ("comm",
+          "comm_note").  MI355SW_BENCH_COMM=host selects that transport outright.
 Rank 0 prints ONE JSON line.  GCUPS convention of the reference: cells = m*n (sw_stage1.cpp:440-448).
 """
 import argparse
@@ -199,7 +203,17 @@ def main():
         # cannot (no peer access between two of the GPUs, IPC refused), ALL ranks use the host transport instead
         ok = torch.tensor([1 if runner.probe_p2p(m) else 0], dtype=torch.int32, device=coll_device)
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-        if int(ok.item()) == 0:
+        usable = int(ok.item()) == 1
+        if usable and os.environ.get("MI355SW_BENCH_VERIFY_P2P", "1") != "0":
+            # ... and a short chain (1 Mi rows) runs once through the ports and once through the host, untimed: every
+            # band must come through within a minute and receive the same column and find the same best cell both
+            # ways (bands.verify_p2p) -- a mapping that opens but does not deliver must not reach the measurement
+            def all_min(v):
+                t = torch.tensor([int(v)], dtype=torch.int32, device=coll_device)
+                dist.all_reduce(t, op=dist.ReduceOp.MIN)
+                return int(t.item())
+            usable = runner.verify_p2p(min(m, 1 << 20), j0, j1, all_min, budget_s=60.0)
+        if not usable:
             comm_note = "p2p unavailable (%s): pinned host columns + gloo instead" % (runner.p2p_error or "a neighbour rank failed")
             comm = "host"
             runner.transport = "host"

@@ -88,7 +88,8 @@ class BandRunner:
         self._in_rows = 0
         self._out_token = None       # handle bytes of the neighbour's port currently mapped
         self.restarts = 0            # packed-kernel overflow restarts (int32 rerun) of the last run
-        self.p2p_error = None        # why probe_p2p() failed on this rank
+        self.p2p_error = None        # why probe_p2p() / verify_p2p() failed on this rank
+        self.inbound_crc = None      # crc32 of the inbound boundary column of the last run(digest_inbound=True)
 
     def _tensor(self, rows):
         import torch
@@ -103,7 +104,7 @@ class BandRunner:
         eng, dist = self.engine, self.dist
         first, last = self.rank == 0, self.rank == self.world - 1
         if not first:
-            if self._in_port is None or self._in_rows != m:
+            if self._in_port is None or self._in_rows < m:     # a port made for a taller matrix serves a shorter one
                 self._in_port, self._in_rows = eng.portCreate(m), m
             else:
                 eng.portReset()
@@ -157,11 +158,58 @@ class BandRunner:
             ok = False
         return ok
 
+    def verify_p2p(self, m, j0, j1, all_min, budget_s=60.0):
+        """Functional check of the port transport before anything is timed: the same short chain (m rows) once
+        through the ports and once through the host.  True only if, on EVERY rank, the port run came through within
+        `budget_s` seconds of waiting and gave the band the same inbound column (crc32) and the same best cell as the
+        host run -- a peer mapping that opens but does not deliver (a kernel that never sees the neighbour's counter
+        move, or sees it move before the cells) shows up here, bounded in time, instead of in the measurement.
+        `all_min(int) -> int` is a collective MIN over the ranks (every rank calls it twice).  On False the caller
+        switches all ranks to transport="host"."""
+        if self.transport != "p2p":
+            return True
+        from .engine import AlignerError
+        saved = {k: os.environ.get(k) for k in ("MI355SW_WAIT_S", "MI355SW_BAND_STALL_S")}
+        os.environ["MI355SW_WAIT_S"] = os.environ["MI355SW_BAND_STALL_S"] = "%g" % budget_s
+        got = {}
+        try:
+            for transport in ("p2p", "host"):
+                self.transport = transport
+                ok = 1
+                try:
+                    best = self.run(m, j0, j1, digest_inbound=True)
+                    got[transport] = (tuple(int(x) for x in best), self.inbound_crc)
+                except Exception as e:          # a wait that ran out, a stalled band, a refused mapping
+                    self.p2p_error = "%s run of the transport check: %s" % (transport, e)
+                    ok = 0
+                    for fn in (self.engine.streamAbort, self.engine.streamEnd):
+                        try:
+                            fn()
+                        except (AlignerError, AttributeError):
+                            pass
+                if all_min(ok) == 0:
+                    return False
+            same = 1 if got["p2p"] == got["host"] else 0
+            if not same:
+                self.p2p_error = "port run and host run of the transport check differ: %r vs %r" % (got["p2p"], got["host"])
+            return all_min(same) == 1
+        finally:
+            self.transport = "p2p"
+            for k, v in saved.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+
     def run(self, m, j0, j1, recurrence=SMITH_WATERMAN, track_best=True, first_row_init_type=INIT_WITH_ZEROES,
             first_col_init_type=INIT_WITH_ZEROES, poll_sleep=0.0005, want_last_row=False, before_end=None,
-            force_int32=False):
-        """seq1 of the engine must already hold the whole horizontal sequence (or at least [j0,j1))."""
+            force_int32=False, digest_inbound=False):
+        """seq1 of the engine must already hold the whole horizontal sequence (or at least [j0,j1)).
+        digest_inbound: leave the crc32 of the boundary column this band received in self.inbound_crc (host transport:
+        the segments as they arrive; p2p: the port's memory, read back once the band is through)."""
+        import zlib
         from .engine import AlignerError
+        self.inbound_crc = 0 if digest_inbound else None
         eng, dist = self.engine, self.dist
         first, last = self.rank == 0, self.rank == self.world - 1
         p2p = self.transport == "p2p"
@@ -203,6 +251,8 @@ class BandRunner:
                     ln = min(seg, m - r0)
                     buf = self._tensor(ln)
                     dist.recv(buf, src=self.rank - 1)
+                    if digest_inbound:
+                        self.inbound_crc = zlib.crc32(buf.numpy().tobytes(), self.inbound_crc)
                     with lock:
                         eng.streamFeedColumn(r0, buf.numpy())
                         fed[0] = r0 + ln
@@ -290,6 +340,8 @@ class BandRunner:
                 time.sleep(poll_sleep)
         if rx is not None:
             rx.join()
+        if digest_inbound and p2p and not first:
+            self.inbound_crc = zlib.crc32(np.ascontiguousarray(eng.portRead(0, m), dtype=np.int32).tobytes())
         if before_end is not None:       # e.g. read this band's slice of the last row while the stream is open
             before_end(eng)
         try:

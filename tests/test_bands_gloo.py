@@ -58,6 +58,12 @@ class OracleStreamEngine:
     def _port_rows(self):
         return int(np.frombuffer(self.in_shm.buf, dtype=np.int32, count=1)[0])
 
+    def portRead(self, row, length):
+        return np.frombuffer(self.in_shm.buf, dtype=np.int32, count=2 * length, offset=256 + 8 * (row + 1)).reshape(-1, 2).copy()
+
+    def streamAbort(self):
+        pass
+
     def streamBegin(self, part, recurrence_type=1, track_best=True, first_row_init_type=0, first_row_start_offset=0,
                     want_last_column=False, first_column_init_type=0, stream_first_column=False, first_column=None,
                     first_column_port=False, last_column_port=False, **kw):
@@ -78,6 +84,7 @@ class OracleStreamEngine:
         self.done = 0
         self.last_col = np.zeros((self.m, 2), dtype=np.int32)
         self.cands = []
+        self.t_wait = None
 
     def streamFeedColumn(self, row, cells):
         assert row == self.fed
@@ -90,10 +97,23 @@ class OracleStreamEngine:
             r1 = min(self.done + self.seg, self.m)
             if self.from_port and self.fed < r1:
                 ready = self._port_rows()               # what the neighbour's "kernel" has published so far
+                if getattr(self, "port_fault", None) == "deaf":
+                    ready = 0                            # a mapping that opens but never delivers
+                if ready <= self.fed:                    # the kernel's wall-time wait budget (csrc/sw_kernel.h)
+                    import time
+                    from masa_cudalign_amd.engine import AlignerError
+                    self.t_wait = self.t_wait or time.time()
+                    if time.time() - self.t_wait > float(os.environ.get("MI355SW_WAIT_S", "3600")):
+                        raise AlignerError("stream_poll: wait budget exhausted on the inbound column")
+                else:
+                    self.t_wait = None
                 if ready > self.fed:
                     cells = np.frombuffer(self.in_shm.buf, dtype=np.int32, count=2 * (ready - self.fed),
                                           offset=256 + 8 * (self.fed + 1)).reshape(-1, 2)
                     self.col[1 + self.fed:1 + ready] = cells
+                    if getattr(self, "port_fault", None) == "stale" and int(cells[:, 0].max()) >= 100:
+                        k = self.fed + int(np.argmax(cells[:, 0])) // 8 * 8
+                        self.col[1 + k:9 + k] = 0        # one 64-byte line seen before its stores had landed
                     self.fed = ready
             if self.fed < r1:
                 return
@@ -236,6 +256,69 @@ def test_p2p_probe_failure_falls_back_to_host_for_everybody(pkg, oracle):
     want = (ref["best"][0] - 1, ref["best"][1] - 1, ref["best"][2])
     assert [res[r][0] for r in range(world)] == [False, False, True]
     assert all(res[r][1] == 0 and res[r][2] == want for r in range(world))
+
+
+def _worker_verify(rank, world, port, m, n, fault, q):
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as graft
+    pkg = graft.load_package()
+    oracle = graft.load_oracle()
+    from masa_cudalign_amd.bands import BandRunner, band_limits
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        s0, s1 = pkg.seqgen.related_pair(m, n, cfg=43)
+        lim = band_limits(n, [1] * world)
+        eng = OracleStreamEngine(oracle, s0, s1, seg=200)
+        if rank == 1:
+            eng.port_fault = fault
+        runner = BandRunner(eng, dist=dist, rank=rank, world=world, device=None, segment_rows=300, transport="p2p")
+
+        def all_min(v):
+            t = torch.tensor([v], dtype=torch.int32)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            return int(t.item())
+        ok = all_min(1 if runner.probe_p2p(m) else 0) == 1
+        verified = ok and runner.verify_p2p(m // 3, lim[rank], lim[rank + 1], all_min, budget_s=3.0)
+        env_restored = "MI355SW_WAIT_S" not in os.environ and "MI355SW_BAND_STALL_S" not in os.environ
+        if not verified:
+            runner.transport = "host"
+            eng.portClose()
+        best = runner.run(m, lim[rank], lim[rank + 1])
+        q.put((rank, verified, runner.transport, env_restored, tuple(runner.reduce_best(best)), runner.p2p_error))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("fault", [None, "stale", "deaf"])
+def test_transport_check_before_the_measurement(pkg, oracle, fault):
+    """bench.py's N > 1 start-up: ports open everywhere, then a short chain runs once through the ports and once
+    through the host and every band compares what it received and what it found.  Healthy ports: the check passes and
+    the run uses them.  A port that delivers a line of cells before its stores landed ("stale"), or never delivers ("deaf":
+    the band's wait budget runs out), fails the check on EVERY rank, within the budget, and the chain falls back to
+    the host transport with the right answer."""
+    m, n, world = 1500, 1400, 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_verify, args=(r, world, port, m, n, fault, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {r[0]: r[1:] for r in (q.get(timeout=240) for _ in range(world))}
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    s0, s1 = pkg.seqgen.related_pair(m, n, cfg=43)
+    ref = oracle.stage1(s0, s1)
+    want = (ref["best"][0] - 1, ref["best"][1] - 1, ref["best"][2])
+    for r in range(world):
+        verified, transport, env_restored, best, err = res[r]
+        assert verified == (fault is None) and transport == ("p2p" if fault is None else "host"), (r, res[r])
+        assert env_restored and best == want, (r, res[r])
+    if fault is not None:
+        assert any(res[r][4] for r in range(world))          # somebody says why
 
 
 def _worker_nw(rank, world, port, m, n, q):
