@@ -8,10 +8,12 @@ executeTraceback() runs after stage 1 (M/libmasa/libmasa.cpp:643-657), with the 
     <work>/status, <work>/alignment.00.txt
 
 The aligner is an MI355Aligner (or anything with its setSequences / alignPartition / matchLastColumn / stage4 /
-unsetSequences); every DP cell of every stage is computed by it.  Untrimmed, unreversed sequences only: --trim and
---reverse shift the coordinates of every stage in MASA-Core and are not carried through stages 2-3 here."""
+unsetSequences); every DP cell of every stage is computed by it.  The sequence modifiers of fasta.py (--trim,
+--reverse, --complement, --clear-n) are carried through all stages as in MASA-Core."""
 import os
 import time
+
+import numpy as np
 
 from .manager import AT_ANYWHERE
 from .engine import INF
@@ -27,20 +29,20 @@ def align(aligner, seq0, seq1, work, alignment_start=AT_ANYWHERE, alignment_end=
     """seq0, seq1: fasta.Sequence.  Returns {"best", "alignment": stage56.Alignment or None, "text": bytes of
     alignment.00.txt or None when nothing scored above the floor, "crosspoints": {2: n, 3: n, 4: n},
     "seconds": {stage: s}}"""
-    for s in (seq0, seq1):
-        if s.modifiers.reverse or s.offset0 != 1 or s.offset1 != s.original_size:
-            raise NotImplementedError("the native pipeline runs untrimmed, unreversed sequences")
-    d0, d1 = seq0.trimmed(), seq1.trimmed()
+    # the data the aligner compares: forward or reversed, complemented, N-cleared (fasta.py); --trim only selects the
+    # part of the matrix stage 1 sweeps, every coordinate of every stage stays absolute (Sequence.cpp:117-159)
+    d0, d1 = np.ascontiguousarray(seq0.data()), np.ascontiguousarray(seq1.data())
+    bounds = (seq0.offset0 - 1, seq1.offset0 - 1, seq0.offset1, seq1.offset1)
     secs = {}
     t = time.time()
     r1 = stage1(aligner, d0, d1, work, alignment_start=alignment_start, alignment_end=alignment_end, sra_limit=sra_limit,
-                block_pruning=block_pruning)
+                block_pruning=block_pruning, bounds=bounds)
     secs[1] = time.time() - t
     out = {"best": r1["best"], "alignment": None, "text": None, "crosspoints": {}, "seconds": secs, "stage1": r1}
     if r1["best"] is None or r1["best"][2] <= -INF or r1["best"][0] < 0:
         return out                                        # an empty best-score list: MASA-Core runs no traceback either
     t = time.time()
-    r2 = stage2(aligner, d0, d1, work, alignment_start=alignment_start, sra_limit=sra_limit)
+    r2 = stage2(aligner, d0, d1, work, alignment_start=alignment_start, sra_limit=sra_limit, bounds=bounds)
     secs[2] = time.time() - t
     t = time.time()
     r3 = stage3(aligner, d0, d1, work, sra_limit=sra_limit)

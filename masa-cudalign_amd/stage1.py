@@ -25,44 +25,53 @@ def border_readers(alignment_start):
 
 
 def stage1(aligner, seq0, seq1, work, alignment_start=AT_ANYWHERE, alignment_end=AT_ANYWHERE, sra_limit=0,
-           block_pruning=True, manager_class=Stage1Manager):
+           block_pruning=True, manager_class=Stage1Manager, bounds=None):
     """Runs (or resumes) stage 1 of seq0 x seq1 in work directory `work`.  `aligner` is an MI355Aligner; create it
     with a fixed strip height (rows_per_lane) when the area must be resumable or shared with CUDAlign: special rows
     sit on multiples of the strip height (1024 or 2048 rows give CUDAlign's 8192-row spacing).
+    `bounds` = (i0, j0, i1, j1): the part of the matrix --trim selects (Sequence::getTrimStart()-1 .. getTrimEnd(),
+    sw_stage1.cpp:281-284); seq0 / seq1 are always the WHOLE sequences, every coordinate (special-row directory,
+    crosspoints, status) stays absolute, and the flush interval is computed from the whole sizes (Job.cpp:62-67).
     Returns {"best": (i, j, score) in 1-based DP coordinates, "resumed_from": row or None, "seconds", "gcups", ...}."""
     m, n = len(seq0), len(seq1)
+    bi0, bj0, bi1, bj1 = bounds if bounds is not None else (0, 0, m, n)
+    if not (0 <= bi0 < bi1 <= m and 0 <= bj0 < bj1 <= n):
+        raise ValueError("stage1: bounds %r outside the %d x %d matrix" % (bounds, m, n))
     os.makedirs(work, exist_ok=True)
     status = sra_mod.Status(work)
     interval = sra_mod.flush_interval(m, n, sra_limit) if sra_limit > 0 else 0
     fr, fc = border_readers(alignment_start)
-    i0, resumed_from, part_sra = 0, None, None
+    i0, resumed_from, part_sra = bi0, None, None
     if sra_limit > 0:
-        part_sra = sra_mod.SpecialRowsPartition(sra_mod.special_rows_path(work, 1, 0), 0, 0, m, n)
+        part_sra = sra_mod.SpecialRowsPartition(sra_mod.special_rows_path(work, 1, 0), bi0, bj0, bi1, bj1)
         last = part_sra.last_row_id()
-        if last == m and status.loaded:
+        if last == bi1 and status.loaded:
             # "Stage 1 was already executed" (sw_stage1.cpp:212-214)
-            return {"best": status.best, "resumed_from": m, "seconds": 0.0, "gcups": 0.0, "already_done": True,
+            return {"best": status.best, "resumed_from": bi1, "seconds": 0.0, "gcups": 0.0, "already_done": True,
                     "special_rows": [r for r in part_sra.rows]}
-        if last != 0:
+        if last != bi0:
             i0, row = part_sra.continue_from_last_row()
-            fc.read(None, i0)                      # firstColumnReader->read(NULL, lastRowId)
+            fc.read(None, i0 - bi0)                # firstColumnReader->read(NULL, lastRowId): rows since the border
             fr = ArrayCellsReader(row)             # FileCellsReader(lastRowFilename): cell 0 = the corner of the rest
             resumed_from = i0
         else:
             part_sra.set_border_markers(fr.getType(), 0, fc.getType(), 0)
-    part = Partition(i0, 0, m, n)
+    part = Partition(i0, bj0, bi1, bj1)
+    sup = Partition(bi0, bj0, bi1, bj1)
+    v0, v1 = seq0[bi0:bi1], seq1[bj0:bj1]       # AlignerManager::setSequences (:168-176): the aligner sees the trimmed data
+    rel = Partition(i0 - bi0, 0, bi1 - bi0, bj1 - bj0)
     mgr = manager_class(part, alignment_start=alignment_start, alignment_end=alignment_end,
                         special_row_interval=interval, first_row_reader=fr, first_column_reader=fc,
-                        super_partition=Partition(0, 0, m, n), block_pruning=block_pruning,
-                        sra_partition=part_sra, status=status)
+                        super_partition=sup, block_pruning=block_pruning,
+                        sra_partition=part_sra, status=status, seq0_offset=bi0, seq1_offset=bj0)
     if status.loaded and status.best is not None and status.best[0] >= 0:
         mgr.best_list.add(*status.best)            # Status::load -> bestScoreList->add (Status.cpp:60-64)
     status.stage = 1
     prefix_value = status.value_best            # left by the run(s) this one continues: strips above row i0
-    aligner.setSequences(seq0, seq1)
+    aligner.setSequences(v0, v1)
     t0 = time.time()
     try:
-        aligner.alignPartition(part, mgr)
+        aligner.alignPartition(rel, mgr)
     finally:
         if part_sra is not None:
             part_sra.close()
@@ -78,17 +87,18 @@ def stage1(aligner, seq0, seq1, work, alignment_start=AT_ANYWHERE, alignment_end
     vb = prefix_value
     if vb is not None and part_sra is not None and (vb[0] > best[2] or (vb[0] == best[2] and vb[1] < best[0])):
         above = [part_sra.i0 + r for r in part_sra.rows if part_sra.i0 + r <= vb[1]]
-        r0 = max(above) if above else 0
+        r0 = max(above) if above else bi0
         fr2, fc2 = border_readers(alignment_start)
-        if r0 > 0:
-            fc2.read(None, r0)
+        if r0 > bi0:
+            fc2.read(None, r0 - bi0)
             fr2 = ArrayCellsReader(part_sra.read_row(r0))
-        sub = Partition(r0, 0, min(vb[2], m), n)
+        sub = Partition(r0, bj0, min(vb[2], bi1), bj1)
         mgr2 = manager_class(sub, alignment_start=alignment_start, alignment_end=alignment_end,
-                             first_row_reader=fr2, first_column_reader=fc2, super_partition=Partition(0, 0, m, n))
-        aligner.setSequences(seq0, seq1)
+                             first_row_reader=fr2, first_column_reader=fc2, super_partition=sup,
+                             seq0_offset=bi0, seq1_offset=bj0)
+        aligner.setSequences(v0, v1)
         try:
-            aligner.alignPartition(sub, mgr2)
+            aligner.alignPartition(Partition(sub.i0 - bi0, 0, sub.i1 - bi0, bj1 - bj0), mgr2)
         finally:
             aligner.unsetSequences()
         located = tuple(mgr2.getBestScore())
@@ -106,6 +116,6 @@ def stage1(aligner, seq0, seq1, work, alignment_start=AT_ANYWHERE, alignment_end
     # else: an empty best-score list -- MASA-Core writes no crosspoint file and runs no traceback (sw_stage1.cpp:481-492: one file per entry of the list)
     st = aligner.getStatistics()
     return {"best": tuple(best), "resumed_from": resumed_from, "seconds": dt,
-            "gcups": float(m - i0) * n / dt / 1e9 if dt > 0 else 0.0, "strip_rows": st["strip_rows"],
+            "gcups": float(bi1 - i0) * (bj1 - bj0) / dt / 1e9 if dt > 0 else 0.0, "strip_rows": st["strip_rows"],
             "kernel_ms": st["kernel_ms"], "pruned_cells": st["pruned_cells"], "located_from_value": located,
             "special_rows": list(part_sra.rows) if part_sra is not None else []}

@@ -65,9 +65,10 @@ def find_next_crosspoint(mgr, area, c0, c1, alignment_start, must_find=True, goa
     return Crosspoint(i, j, score, typ)
 
 
-def stage2(aligner, seq0, seq1, work, alignment_start=AT_ANYWHERE, sra_limit=0, ident=0):
+def stage2(aligner, seq0, seq1, work, alignment_start=AT_ANYWHERE, sra_limit=0, ident=0, bounds=None):
     """Runs stage 2 for alignment `ident` of work directory `work` (stage 1 must have left crosspoint_01.NN and,
-    with sra_limit > 0, its special rows there).  Returns {"crosspoints": [(type, i, j, score), ...] as written to
+    with sra_limit > 0, its special rows there).  seq0 / seq1: the whole sequences; `bounds` = (i0, j0, i1, j1) the
+    part --trim selected for stage 1 (only its origin matters here: where a global alignment must begin).  Returns {"crosspoints": [(type, i, j, score), ...] as written to
     crosspoint_02.NN, "end": the last crosspoint in ORIGINAL coordinates, "partitions", "seconds"}."""
     t_start = time.time()
     s0, s1 = _as_u8(seq0), _as_u8(seq1)
@@ -75,6 +76,7 @@ def stage2(aligner, seq0, seq1, work, alignment_start=AT_ANYWHERE, sra_limit=0, 
     seq_v = np.ascontiguousarray(s1[::-1])               # sw_stage2.cpp:258-276: reverse = 1
     seq_h = np.ascontiguousarray(s0[::-1])
     len_v, len_h = n, m
+    bi0, bj0, bi1, bj1 = bounds if bounds is not None else (0, 0, m, n)
     area1 = sra_mod.SpecialRowsArea(sra_mod.special_rows_path(work, 1, 0))
     area2 = sra_mod.SpecialRowsArea(sra_mod.special_rows_path(work, 2, ident))
     cps1 = CrosspointsFile(crosspoint_file(work, 1, ident)).load()
@@ -83,7 +85,7 @@ def stage2(aligner, seq0, seq1, work, alignment_start=AT_ANYWHERE, sra_limit=0, 
     cps1.reverse_all(len_h, len_v)                       # :294
     cp = cps1[0].copy()
     cp_r = cp.reverse(len_v, len_h)                      # back in stage 1's coordinates
-    if (cp_r.j <= 0 or cp_r.j > n) and cp_r.j != 0:     # :299-305: not this process's columns
+    if (cp_r.j <= bj0 or cp_r.j > bj1) and cp_r.j != bj0:     # :299-305: not this process's columns
         return {"crosspoints": [], "end": cp_r.astuple(), "partitions": 0, "seconds": 0.0}
     part1 = area1.open_partition_at(cp_r.i, cp_r.j)
     mgr = AlignerManager(aligner)
@@ -134,7 +136,7 @@ def stage2(aligner, seq0, seq1, work, alignment_start=AT_ANYWHERE, sra_limit=0, 
         if cp.score != 0:
             # :461-481: a global / semi-global alignment that reached a gap-initialised border away from the origin
             # runs along that border to the origin
-            origin_r = Crosspoint(0, 0, 0, TYPE_MATCH)
+            origin_r = Crosspoint(bi0, bj0, 0, TYPE_MATCH)
             gapped = (INIT_WITH_GAPS, INIT_WITH_GAPS_OPENED)
             if ((col_reader is not None and col_reader.getType() in gapped and cp_r.j == origin_r.j and cp_r.i != origin_r.i) or
                     (row_reader is not None and row_reader.getType() in gapped and cp_r.i == origin_r.i and cp_r.j != origin_r.j)):

@@ -221,6 +221,12 @@ static int parse_edge(char c) {
     exit(2);
 }
 
+/* parse_sequence_flags, libmasa.cpp: none | 1 | 2 | both */
+static void parse_seq_flags(const char* s, bool* flags) {
+    flags[0] = (!strcmp(s, "1") || !strcmp(s, "both"));
+    flags[1] = (!strcmp(s, "2") || !strcmp(s, "both"));
+}
+
 static long long parse_size(const char* s) {
     char* end;
     double v = strtod(s, &end);
@@ -235,6 +241,7 @@ static long long parse_size(const char* s) {
  *   --work-dir=DIR --stage-1 --edges=XY --disk-size=N[KMG] --no-flush
  *   --no-block-pruning --block=H,W --split=COUNT --part=STEP
  *   --flush-column=URL --load-column=URL --max-alignments=N
+ *   --trim=I0,I1,J0,J1 --clear-n --reverse=1|2|both --complement=1|2|both --reverse-complement=1|2|both
  */
 int main(int argc, char** argv) {
     std::string work = "./work.tmp";
@@ -251,6 +258,8 @@ int main(int argc, char** argv) {
     std::vector<int> fork_weights;
     std::vector<const char*> files;
     std::vector<char*> extension_args;
+    int trim_start[2] = {0, 0}, trim_end[2] = {0, 0};
+    bool clear_n = false, reverse_seq[2] = {false, false}, complement_seq[2] = {false, false};
 
     for (int a = 1; a < argc; a++) {
         const char* s = argv[a];
@@ -267,6 +276,12 @@ int main(int argc, char** argv) {
         else if (!strncmp(s, "--flush-column=", 15)) { flush_url = s + 15; pruning = false; }
         else if (!strncmp(s, "--load-column=", 14)) { load_url = s + 14; pruning = false; }
         else if (!strncmp(s, "--max-alignments=", 17)) max_alignments = atoi(s + 17);
+        /* sequence modifiers, libmasa.cpp:986-1050 */
+        else if (!strncmp(s, "--trim=", 7)) sscanf(s + 7, "%d,%d,%d,%d", &trim_start[0], &trim_end[0], &trim_start[1], &trim_end[1]);
+        else if (!strcmp(s, "--clear-n")) clear_n = true;
+        else if (!strncmp(s, "--reverse=", 10)) parse_seq_flags(s + 10, reverse_seq);
+        else if (!strncmp(s, "--complement=", 13)) parse_seq_flags(s + 13, complement_seq);
+        else if (!strncmp(s, "--reverse-complement=", 21)) { parse_seq_flags(s + 21, complement_seq); reverse_seq[0] = complement_seq[0]; reverse_seq[1] = complement_seq[1]; }
         else if (!strcmp(s, "--gpu-stage4")) gpu_stage4 = true;               /* product stage 4 instead of MASA-Core's */
         else if (!strcmp(s, "--fork")) do_fork = true;                       /* weights from IAligner::getForkWeights */
         else if (!strncmp(s, "--fork=", 7)) {                                /* --fork=W1,W2,... (libmasa.cpp:964-980) */
@@ -325,11 +340,11 @@ int main(int argc, char** argv) {
         SequenceInfo* info = new SequenceInfo();
         info->setFilename(files[i]);
         SequenceModifiers* mod = new SequenceModifiers();
-        mod->setClearN(false);
-        mod->setReverse(false);
-        mod->setComplement(false);
-        mod->setTrimStart(0);
-        mod->setTrimEnd(0);
+        mod->setClearN(clear_n);
+        mod->setReverse(reverse_seq[i]);
+        mod->setComplement(complement_seq[i]);
+        mod->setTrimStart(trim_start[i]);
+        mod->setTrimEnd(trim_end[i]);
         Sequence* seq = new Sequence(info, mod);
         job->addSequence(seq);
         ap->addSequence(seq);

@@ -140,6 +140,73 @@ def test_stages_1_to_3_against_the_live_reference(name, pair, bh, bw, limit, edg
         assert len(r2["crosspoints"]) == 1 and r2["partitions"] == 0
 
 
+def _revcomp(a):
+    comp = np.arange(256, dtype=np.uint8)
+    for x, y in ((65, 84), (84, 65), (67, 71), (71, 67)):
+        comp[x] = y
+    return np.ascontiguousarray(comp[a][::-1])
+
+
+def _with_n(pkg):
+    s0, s1 = pkg.seqgen.related_pair(3000, 2700, cfg=1)
+    s0, s1 = s0.copy(), s1.copy()
+    s0[1000:1040] = ord("N")
+    s1[1005:1030] = ord("N")
+    return s0, s1
+
+
+MODS = [
+    # name, pair, reference flags, modifiers of sequence 0, of sequence 1
+    ("trim", lambda pkg: pkg.seqgen.related_pair(3000, 2700, cfg=1), ["--trim=201,2500,101,2600"],
+     dict(trim_start=201, trim_end=2500), dict(trim_start=101, trim_end=2600)),
+    ("trim_open_ends", lambda pkg: pkg.seqgen.related_pair(3000, 2700, cfg=1), ["--trim=0,2500,300,0"],
+     dict(trim_end=2500), dict(trim_start=300)),
+    ("reverse_complement_2", lambda pkg: (lambda p: (p[0], _revcomp(p[1])))(pkg.seqgen.related_pair(3000, 2700, cfg=1)),
+     ["--reverse-complement=2"], dict(), dict(reverse=True, complement=True)),
+    ("reverse_complement_2_trimmed", lambda pkg: (lambda p: (p[0], _revcomp(p[1])))(pkg.seqgen.related_pair(3000, 2700, cfg=1)),
+     ["--reverse-complement=2", "--trim=100,2900,50,2650"], dict(trim_start=100, trim_end=2900),
+     dict(reverse=True, complement=True, trim_start=50, trim_end=2650)),
+    ("reverse_both", lambda pkg: tuple(np.ascontiguousarray(x[::-1]) for x in pkg.seqgen.related_pair(3000, 2700, cfg=1)),
+     ["--reverse=both"], dict(reverse=True), dict(reverse=True)),
+    ("clear_n", _with_n, ["--clear-n"], dict(clear_n=True), dict(clear_n=True)),
+    ("n_kept", _with_n, [], dict(), dict()),
+]
+
+
+@pytest.mark.parametrize("name,pair,flags,mod0,mod1", MODS, ids=[x[0] for x in MODS])
+def test_sequence_modifiers_through_all_stages(name, pair, flags, mod0, mod1, pkg, oracle, tmp_path):
+    """--trim, --reverse, --complement, --clear-n from the FASTA view (fasta.py) through stages 1-6: trimming only
+    selects the part of the matrix stage 1 sweeps, all coordinates stay absolute; every crosspoint file, the
+    special-rows directories and alignment.00.txt (header with the trimmed range, positions of the reversed strand)
+    equal MASA-Core's"""
+    if not oracle.have_ref():
+        pytest.skip("oracle/_ref not built (needs /root/reference)")
+    from oracle.aligner_double import SerialBlockAligner
+    from masa_cudalign_amd import fasta, pipeline
+    s0, s1 = pair(pkg)
+    limit = 200 * 1024
+    refdir = tmp_path / "ref"
+    refdir.mkdir()
+    ref = oracle.run_ref(s0, s1, ["--disk-size=%d" % limit, "--block=128,128", "--no-block-pruning"] + flags,
+                         workdir=str(refdir), timeout=600)
+    rwork = str(refdir / "work")
+    q0 = fasta.parse(b">s0\n" + s0.tobytes() + b"\n", fasta.SequenceModifiers(**mod0))
+    q1 = fasta.parse(b">s1\n" + s1.tobytes() + b"\n", fasta.SequenceModifiers(**mod1))
+    work = str(tmp_path / "native")
+    out = pipeline.align(SerialBlockAligner(128, 128), q0, q1, work, sra_limit=limit, block_pruning=False)
+    assert tuple(out["best"]) == tuple(ref["best"])
+    for f in sorted(os.listdir(os.path.join(rwork, "crosspoints"))):
+        assert filecmp.cmp(os.path.join(rwork, "crosspoints", f), os.path.join(work, "crosspoints", f), shallow=False), f
+    assert out["text"] == ref["alignment_txt"]
+    last_row = "%08X" % (q0.offset1 - (q0.offset0 - 1))      # the native stage 1's completion marker (manager.py)
+    for d in sorted(os.listdir(os.path.join(rwork, "special_rows"))):
+        p = subprocess.run(["diff", "-rq", "-x", last_row, os.path.join(rwork, "special_rows", d),
+                            os.path.join(work, "special_rows", d)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+        assert p.returncode == 0, p.stdout.decode()[:2000]
+    if "trim" in name:
+        assert b"[" in out["text"].split(b"\n")[0]           # "Query: s0 [201..2500](2300)"
+
+
 def test_nothing_to_trace_back(pkg, oracle, tmp_path):
     """a global start with a local end and nothing above the floor: MASA-Core's best-score list stays empty, it writes
     no crosspoint file and runs no traceback; neither does the native pipeline"""
