@@ -207,6 +207,49 @@ def test_sequence_modifiers_through_all_stages(name, pair, flags, mod0, mod1, pk
         assert b"[" in out["text"].split(b"\n")[0]           # "Query: s0 [201..2500](2300)"
 
 
+def test_native_stages_continue_a_work_directory_of_masa_core(pkg, oracle, tmp_path):
+    """the formats are shared, so either side can pick up where the other stopped: stage 2 natively on the special
+    rows and the crosspoint MASA-Core's stage 1 wrote (block pruning on), stage 3 natively on what MASA-Core's stage 2
+    wrote -- each reproduces the file MASA-Core's own next stage produced"""
+    if not oracle.have_ref():
+        pytest.skip("oracle/_ref not built (needs /root/reference)")
+    import shutil
+    from oracle.aligner_double import SerialBlockAligner
+    from masa_cudalign_amd.stage2 import stage2
+    from masa_cudalign_amd.stage3 import stage3
+    s0, s1 = pkg.seqgen.related_pair(12000, 12000, cfg=21, p_indel=0.02, indel_mean=6.0)
+    limit = 300 * 1024
+    refdir = tmp_path / "ref"
+    refdir.mkdir()
+    oracle.run_ref(s0, s1, ["--disk-size=%d" % limit, "--block=128,128"], workdir=str(refdir), timeout=600)
+    rwork = str(refdir / "work")
+    want2 = open(os.path.join(rwork, "crosspoints", "crosspoint_02.00"), "rb").read()
+    want3 = open(os.path.join(rwork, "crosspoints", "crosspoint_03.00"), "rb").read()
+    al = SerialBlockAligner(128, 128)
+    # (a) stage 3 on MASA-Core's stage-2 output
+    wa = str(tmp_path / "a")
+    shutil.copytree(rwork, wa)
+    shutil.rmtree(os.path.join(wa, "special_rows", "stage.03.00.r01"))
+    for f in os.listdir(os.path.join(wa, "crosspoints")):
+        if f.startswith("crosspoint_03") or f.startswith("crosspoint_04"):
+            os.remove(os.path.join(wa, "crosspoints", f))
+    stage3(al, s0, s1, wa, sra_limit=limit)
+    assert open(os.path.join(wa, "crosspoints", "crosspoint_03.00"), "rb").read() == want3
+    # (b) stages 2 and 3 on MASA-Core's stage-1 output
+    wb = str(tmp_path / "b")
+    shutil.copytree(rwork, wb)
+    for d in os.listdir(os.path.join(wb, "special_rows")):
+        if not d.startswith("stage.01"):
+            shutil.rmtree(os.path.join(wb, "special_rows", d))
+    for f in os.listdir(os.path.join(wb, "crosspoints")):
+        if not f.startswith("crosspoint_01"):
+            os.remove(os.path.join(wb, "crosspoints", f))
+    stage2(al, s0, s1, wb, sra_limit=limit)
+    assert open(os.path.join(wb, "crosspoints", "crosspoint_02.00"), "rb").read() == want2
+    stage3(al, s0, s1, wb, sra_limit=limit)
+    assert open(os.path.join(wb, "crosspoints", "crosspoint_03.00"), "rb").read() == want3
+
+
 def test_nothing_to_trace_back(pkg, oracle, tmp_path):
     """a global start with a local end and nothing above the floor: MASA-Core's best-score list stays empty, it writes
     no crosspoint file and runs no traceback; neither does the native pipeline"""
