@@ -56,6 +56,11 @@ def stage1(aligner, seq0, seq1, work, alignment_start=AT_ANYWHERE, alignment_end
             resumed_from = i0
         else:
             part_sra.set_border_markers(fr.getType(), 0, fc.getType(), 0)
+    else:
+        # no budget for special rows: the partition's directory and border markers still exist, as MASA-Core's
+        # (SpecialRowsArea::createSplittedPartitions) -- stage 2 then walks back over ONE partition, to its first row
+        sra_mod.SpecialRowsPartition(sra_mod.special_rows_path(work, 1, 0), bi0, bj0, bi1, bj1).set_border_markers(
+            fr.getType(), 0, fc.getType(), 0)
     part = Partition(i0, bj0, bi1, bj1)
     sup = Partition(bi0, bj0, bi1, bj1)
     v0, v1 = seq0[bi0:bi1], seq1[bj0:bj1]       # AlignerManager::setSequences (:168-176): the aligner sees the trimmed data

@@ -93,6 +93,7 @@ LIVE = [
     ("contained_swapped_12", lambda pkg: _contained(pkg)[::-1], 128, 256, 150 * 1024, "12"),
     ("contained_swapped_global", lambda pkg: _contained(pkg)[::-1], 128, 256, 150 * 1024, "22"),
     ("no_traceback_13", _contained, 128, 128, 150 * 1024, "13"),
+    ("no_budget_for_special_rows", lambda pkg: pkg.seqgen.related_pair(3000, 2700, cfg=1), 128, 128, 0, "**"),
 ]
 
 
