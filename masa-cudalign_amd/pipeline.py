@@ -25,7 +25,7 @@ from . import stage56
 
 
 def align(aligner, seq0, seq1, work, alignment_start=AT_ANYWHERE, alignment_end=AT_ANYWHERE, sra_limit=0,
-          block_pruning=True, max_partition_size=16):
+          block_pruning=True, max_partition_size=16, progress=None):
     """seq0, seq1: fasta.Sequence.  Returns {"best", "alignment": stage56.Alignment or None, "text": bytes of
     alignment.00.txt or None when nothing scored above the floor, "crosspoints": {2: n, 3: n, 4: n},
     "seconds": {stage: s}}"""
@@ -36,7 +36,7 @@ def align(aligner, seq0, seq1, work, alignment_start=AT_ANYWHERE, alignment_end=
     secs = {}
     t = time.time()
     r1 = stage1(aligner, d0, d1, work, alignment_start=alignment_start, alignment_end=alignment_end, sra_limit=sra_limit,
-                block_pruning=block_pruning, bounds=bounds)
+                block_pruning=block_pruning, bounds=bounds, progress=progress)
     secs[1] = time.time() - t
     out = {"best": r1["best"], "alignment": None, "text": None, "crosspoints": {}, "seconds": secs, "stage1": r1}
     if r1["best"] is None or r1["best"][2] <= -INF or r1["best"][0] < 0:

@@ -24,14 +24,47 @@ def border_readers(alignment_start):
     return InitialCellsReader(GAP_OPEN, GAP_EXT), InitialCellsReader(GAP_OPEN, GAP_EXT)
 
 
+def progress_line(seconds, best, progress_string):
+    """the line MASA-Core prints every two seconds (logStatus, sw_stage1.cpp:120-127)"""
+    t = int(seconds)
+    return "(%dh%02dm%02ds) best:(%d,%d,%d) %s" % (t // 3600, (t % 3600) // 60, t % 60, best[0], best[1], best[2], progress_string)
+
+
+def _start_progress_log(aligner, mgr, stream, interval, t0):
+    """a timer thread next to the blocking alignPartition call (the reference's RecurrentTimer); the engine's progress
+    string is read with one atomic load (mi355sw_progress), the manager's best score list is only looked at"""
+    if stream is None or not hasattr(aligner, "getProgressString"):
+        return lambda: None
+    import threading
+    done = threading.Event()
+
+    def loop():
+        while not done.wait(interval):
+            try:
+                stream.write(progress_line(time.time() - t0, mgr.getBestScore(), aligner.getProgressString()) + "\n")
+                stream.flush()
+            except Exception:          # a logger must never take the run down
+                return
+    th = threading.Thread(target=loop, daemon=True)
+    th.start()
+
+    def stop():
+        done.set()
+        th.join(timeout=5.0)
+    return stop
+
+
 def stage1(aligner, seq0, seq1, work, alignment_start=AT_ANYWHERE, alignment_end=AT_ANYWHERE, sra_limit=0,
-           block_pruning=True, manager_class=Stage1Manager, bounds=None):
+           block_pruning=True, manager_class=Stage1Manager, bounds=None, progress=None, progress_interval=2.0):
     """Runs (or resumes) stage 1 of seq0 x seq1 in work directory `work`.  `aligner` is an MI355Aligner; create it
     with a fixed strip height (rows_per_lane) when the area must be resumable or shared with CUDAlign: special rows
     sit on multiples of the strip height (1024 or 2048 rows give CUDAlign's 8192-row spacing).
     `bounds` = (i0, j0, i1, j1): the part of the matrix --trim selects (Sequence::getTrimStart()-1 .. getTrimEnd(),
     sw_stage1.cpp:281-284); seq0 / seq1 are always the WHOLE sequences, every coordinate (special-row directory,
     crosspoints, status) stays absolute, and the flush interval is computed from the whole sizes (Job.cpp:62-67).
+    `progress`: a text stream (sys.stderr) that gets MASA-Core's progress line every `progress_interval` seconds while
+    the aligner runs -- "(0h00m02s) best:(i,j,score) PROGRESS: d/D strips" (logStatus, sw_stage1.cpp:112-128; the status
+    file itself is saved with every completed special row, not by this timer).
     Returns {"best": (i, j, score) in 1-based DP coordinates, "resumed_from": row or None, "seconds", "gcups", ...}."""
     m, n = len(seq0), len(seq1)
     bi0, bj0, bi1, bj1 = bounds if bounds is not None else (0, 0, m, n)
@@ -75,9 +108,11 @@ def stage1(aligner, seq0, seq1, work, alignment_start=AT_ANYWHERE, alignment_end
     prefix_value = status.value_best            # left by the run(s) this one continues: strips above row i0
     aligner.setSequences(v0, v1)
     t0 = time.time()
+    stop_log = _start_progress_log(aligner, mgr, progress, progress_interval, t0)
     try:
         aligner.alignPartition(rel, mgr)
     finally:
+        stop_log()
         if part_sra is not None:
             part_sra.close()
         aligner.unsetSequences()

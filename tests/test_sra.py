@@ -167,3 +167,22 @@ def test_status_file_round_trip(pkg, tmp_path):
     assert not os.path.exists(os.path.join(str(tmp_path), "status.tmp"))
     again = pkg.sra.Status(str(tmp_path))
     assert again.loaded and (again.stage, again.last_special_row, again.best) == (1, 16384, (9004, 9000, 8091))
+
+
+def test_progress_line_of_stage1(pkg, oracle, tmp_path):
+    """MASA-Core's two-second progress line (logStatus, sw_stage1.cpp:112-128) from the native stage 1: a timer thread
+    next to the blocking aligner call"""
+    import io
+    from oracle.aligner_double import SerialBlockAligner
+    from masa_cudalign_amd.stage1 import stage1, progress_line
+    assert progress_line(3725.9, (1, 2, 3), "PROGRESS: 5/10 strips") == "(1h02m05s) best:(1,2,3) PROGRESS: 5/10 strips"
+
+    class Aligner(SerialBlockAligner):
+        def getProgressString(self):
+            return "PROGRESS: %d cells" % self.cells
+    s0, s1 = pkg.seqgen.related_pair(9000, 9000, cfg=3)
+    buf = io.StringIO()
+    r = stage1(Aligner(128, 128), s0, s1, str(tmp_path / "w"), progress=buf, progress_interval=0.05, block_pruning=False)
+    lines = buf.getvalue().splitlines()
+    assert lines and all(ln.startswith("(0h00m0") and " best:(" in ln and "PROGRESS: " in ln for ln in lines)
+    assert r["best"][2] == oracle.stage1(s0, s1)["best"][2]

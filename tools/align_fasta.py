@@ -73,11 +73,12 @@ def main(argv):
         if only1:
             bounds = (seqs[0].offset0 - 1, seqs[1].offset0 - 1, seqs[0].offset1, seqs[1].offset1)
             r = stage1.stage1(al, seqs[0].data(), seqs[1].data(), work, alignment_start=edge[edges[0]],
-                              alignment_end=edge[edges[1]], sra_limit=limit, block_pruning=prune, bounds=bounds)
+                              alignment_end=edge[edges[1]], sra_limit=limit, block_pruning=prune, bounds=bounds,
+                              progress=sys.stderr)
             res = {"best": list(r["best"]), "seconds": {"1": r["seconds"]}, "gcups": r["gcups"]}
         else:
             out = pipeline.align(al, seqs[0], seqs[1], work, alignment_start=edge[edges[0]], alignment_end=edge[edges[1]],
-                                 sra_limit=limit, block_pruning=prune)
+                                 sra_limit=limit, block_pruning=prune, progress=sys.stderr)
             res = {"best": list(out["best"]), "seconds": {str(k): v for k, v in out["seconds"].items()},
                    "crosspoints": {str(k): v for k, v in out["crosspoints"].items()},
                    "alignment": os.path.join(work, "alignment.00.txt") if out["text"] else None}
