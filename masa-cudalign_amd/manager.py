@@ -441,6 +441,7 @@ class AlignerManager:
             self.found = True
             return r
         if r["type"] < 0:
+            self.active = False          # inside an engine callback the exception only surfaces after the call: stop the sweep
             raise BacktraceLost("backtrace lost (%d): border sum above the goal %d at cell %d of a chunk of %d"
                                 % (r["type"], self.goal_score, r["k"], length))
         return None
