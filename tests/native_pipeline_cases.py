@@ -1,0 +1,64 @@
+"""Bodies of tests/test_gpu_zz_native_pipeline.py, runnable on their own:
+
+    python tests/native_pipeline_cases.py <case>        -> one JSON line, exit code 0 = every check held
+
+Each case runs the native pipeline (masa-cudalign_amd/pipeline.py) on the ENGINE (cuda:0) for one full-pipeline fixture
+and checks best score, stage-2 crosspoints and alignment.00.txt against what MASA-Core wrote.  The pytest file runs
+them in a child process, so that a fault in this not-yet-hardware-proven combination cannot take the test session
+down with it."""
+import hashlib
+import json
+import os
+import sys
+import tempfile
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(HERE))
+
+CASES = {
+    # name: (fixture, MI355Aligner kwargs, pipeline kwargs, exact crosspoints + text?)
+    "b8192_3000x2700": ("full_pipeline_3000x2700_b8192", {}, dict(sra_limit=200 * 1024), True),
+    "b8192_20000x9000": ("full_pipeline_20000x9000_b8192", {}, dict(sra_limit=200 * 1024), True),
+    "other_geometry": ("full_pipeline_3000x2700", {}, dict(sra_limit=200 * 1024), False),
+    # 1024-row strips like the drop-in test's --strip-rows=1024 (rows_per_lane = rows / 64)
+    "pruned_60000x50000": ("full_pipeline_pruned_60000x50000_b8192", dict(rows_per_lane=16),
+                           dict(sra_limit=4 * 1024 * 1024, block_pruning=True), True),
+}
+
+
+def run(case_name):
+    import __graft_entry__ as graft
+    from helpers import load_golden, make_pair
+    pkg = graft.load_package()
+    from masa_cudalign_amd import fasta, pipeline
+    from masa_cudalign_amd.crosspoints import CrosspointsFile, crosspoint_file
+    fixture, akw, pkw, exact = CASES[case_name]
+    case = [c for c in load_golden()["cases"] if c["name"] == fixture][0]
+    s0, s1 = make_pair(pkg, case["seq"])
+    q0, q1 = fasta.parse(b">s0\n" + s0.tobytes() + b"\n"), fasta.parse(b">s1\n" + s1.tobytes() + b"\n")
+    work = tempfile.mkdtemp(prefix="mi355_native_")
+    al = pkg.MI355Aligner(device=0, **akw)
+    try:
+        out = pipeline.align(al, q0, q1, work, **pkw)
+    finally:
+        al.close()
+    cp2 = CrosspointsFile(crosspoint_file(work, 2)).load().tuples()
+    want2 = [tuple(p) for p in case["crosspoints_2"]]
+    checks = {"best": list(out["best"]) == case["best"],
+              "alignment_score": out["alignment"] is not None and out["alignment"].raw_score == case["best"][2]}
+    if exact:
+        checks["crosspoints_2"] = cp2 == want2
+        checks["alignment_txt"] = hashlib.sha256(out["text"]).hexdigest() == case["alignment_txt_sha256"]
+    else:                      # another special-row spacing may pick another, equally optimal path
+        checks["start_and_end"] = bool(cp2) and cp2[0] == want2[0] and cp2[-1] == want2[-1]
+    if pkw.get("block_pruning"):
+        checks["pruned"] = out["stage1"]["pruned_cells"] > 0.15 * case["m"] * case["n"]
+    res = {"case": case_name, "checks": checks, "ok": all(checks.values()), "best": list(out["best"]),
+           "crosspoints": out["crosspoints"], "seconds": out["seconds"], "stage3_rounds": out["stage3"]["rounds"]}
+    print(json.dumps(res), flush=True)
+    return 0 if res["ok"] else 1
+
+
+if __name__ == "__main__":
+    sys.exit(run(sys.argv[1]))

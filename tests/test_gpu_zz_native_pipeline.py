@@ -6,81 +6,57 @@ The same drivers are pinned on the CPU against MASA-Core byte for byte (tests/te
 double); the same engine calls are made by MASA-Core's own stages 2-3 in tests/test_gpu_dropin.py.  What is new here is
 the combination -- the Python AlignerManager as the engine's callback table.
 
-WRITTEN AT THE END OF ROUND 2 WITH NO GPU MINUTES LEFT: this file has not run on an MI355X yet.  It is therefore
-skipped unless MI355SW_NATIVE_PIPELINE=1 is set; the first GPU call of the next round runs it and removes the gate
-(the file sorts last so that, once enabled, it cannot hide another test behind `-x`)."""
-import hashlib
+WRITTEN AT THE END OF ROUND 2 WITH NO GPU MINUTES LEFT: nothing in this file had run on an MI355X when it was
+committed.  Until it has been green once on hardware, every case runs in a CHILD process with a time limit
+(tests/native_pipeline_cases.py), and a case that does not hold is reported as XFAIL with the child's output instead
+of failing the session -- a pass is a real pass.  MI355SW_NATIVE_PIPELINE=1 makes failures count (what round 3 sets
+once the cases are green, before this paragraph is deleted).  The file sorts last."""
+import json
 import os
+import subprocess
+import sys
 
 import pytest
 
-from helpers import load_golden, make_pair
+pytestmark = pytest.mark.gpu
 
-pytestmark = [pytest.mark.gpu,
-              pytest.mark.skipif(os.environ.get("MI355SW_NATIVE_PIPELINE") != "1",
-                                 reason="native stages 2-3 on the engine: not yet run on an MI355X (set MI355SW_NATIVE_PIPELINE=1)")]
-
-G = load_golden()
+HERE = os.path.dirname(os.path.abspath(__file__))
+STRICT = os.environ.get("MI355SW_NATIVE_PIPELINE") == "1"
 
 
-def _fasta(pkg, s0, s1):
-    from masa_cudalign_amd import fasta
-    return fasta.parse(b">s0\n" + s0.tobytes() + b"\n"), fasta.parse(b">s1\n" + s1.tobytes() + b"\n")
+def _case(name, limit_s=900):
+    try:
+        p = subprocess.run([sys.executable, os.path.join(HERE, "native_pipeline_cases.py"), name], stdout=subprocess.PIPE,
+                           stderr=subprocess.STDOUT, timeout=limit_s)
+        rc, log = p.returncode, p.stdout.decode(errors="replace")
+    except subprocess.TimeoutExpired as e:
+        rc, log = -1, "timed out after %d s\n%s" % (limit_s, (e.stdout or b"").decode(errors="replace"))
+    if rc != 0:
+        msg = "native pipeline case %s: exit code %d\n%s" % (name, rc, log[-3000:])
+        if STRICT:
+            pytest.fail(msg)
+        pytest.xfail("first hardware run of the native stages 2-3 (see the file's header): " + msg)
+    res = json.loads([ln for ln in log.splitlines() if ln.startswith("{")][-1])
+    assert res["ok"] and all(res["checks"].values()), res
+    return res
 
 
-@pytest.mark.parametrize("name", ["full_pipeline_3000x2700_b8192", "full_pipeline_20000x9000_b8192"])
-def test_native_pipeline_on_the_engine(pkg, name, tmp_path):
+@pytest.mark.parametrize("name", ["b8192_3000x2700", "b8192_20000x9000"])
+def test_native_pipeline_on_the_engine(name):
     """fixtures made with the engine's special-row spacing (8192 rows): the traceback coincides byte for byte"""
-    from masa_cudalign_amd import pipeline
-    from masa_cudalign_amd.crosspoints import CrosspointsFile, crosspoint_file
-    case = [c for c in G["cases"] if c["name"] == name][0]
-    s0, s1 = make_pair(pkg, case["seq"])
-    q0, q1 = _fasta(pkg, s0, s1)
-    work = str(tmp_path / "work")
-    al = pkg.MI355Aligner(device=0)
-    try:
-        out = pipeline.align(al, q0, q1, work, sra_limit=200 * 1024)
-    finally:
-        al.close()
-    assert list(out["best"]) == case["best"]
-    assert CrosspointsFile(crosspoint_file(work, 2)).load().tuples() == [tuple(p) for p in case["crosspoints_2"]]
-    assert hashlib.sha256(out["text"]).hexdigest() == case["alignment_txt_sha256"]
-    assert out["alignment"].raw_score == case["best"][2]
+    res = _case(name)
+    assert {"best", "crosspoints_2", "alignment_txt", "alignment_score"} <= set(res["checks"])
 
 
-def test_native_pipeline_other_geometry_same_optimum(pkg, tmp_path):
+def test_native_pipeline_other_geometry_same_optimum():
     """against the fixture made with 128-row blocks: another spacing may pick another, equally optimal path -- score,
-    start and end of the alignment are the same, and the text re-scores itself to the best score"""
-    from masa_cudalign_amd import pipeline
-    case = [c for c in G["cases"] if c["name"] == "full_pipeline_3000x2700"][0]
-    s0, s1 = make_pair(pkg, case["seq"])
-    q0, q1 = _fasta(pkg, s0, s1)
-    al = pkg.MI355Aligner(device=0)
-    try:
-        out = pipeline.align(al, q0, q1, str(tmp_path / "work"), sra_limit=200 * 1024)
-    finally:
-        al.close()
-    assert list(out["best"]) == case["best"]
-    cp2 = out["stage2"]["crosspoints"]
-    assert cp2[0] == tuple(case["crosspoints_2"][0]) and cp2[-1] == tuple(case["crosspoints_2"][-1])
-    assert out["alignment"].raw_score == case["best"][2]
+    start and end of the alignment are the same, and stage 5 re-scores the path to the best score"""
+    res = _case("other_geometry")
+    assert res["checks"]["start_and_end"]
 
 
-def test_native_pipeline_with_pruning_biting(pkg, tmp_path):
+def test_native_pipeline_with_pruning_biting():
     """60000 x 50000 with block pruning on in stage 1: the special rows are lower bounds off the optimal path, the
     traceback on top of them recovers the reference's crosspoints and text"""
-    from masa_cudalign_amd import pipeline
-    from masa_cudalign_amd.crosspoints import CrosspointsFile, crosspoint_file
-    case = [c for c in G["cases"] if c["name"] == "full_pipeline_pruned_60000x50000_b8192"][0]
-    s0, s1 = make_pair(pkg, case["seq"])
-    q0, q1 = _fasta(pkg, s0, s1)
-    work = str(tmp_path / "work")
-    al = pkg.MI355Aligner(device=0, rows_per_lane=16)         # 1024-row strips: the drop-in test's --strip-rows=1024 (rows / 64)
-    try:
-        out = pipeline.align(al, q0, q1, work, sra_limit=4 * 1024 * 1024, block_pruning=True)
-    finally:
-        al.close()
-    assert list(out["best"]) == case["best"]
-    assert out["stage1"]["pruned_cells"] > 0.15 * case["m"] * case["n"]
-    assert CrosspointsFile(crosspoint_file(work, 2)).load().tuples() == [tuple(p) for p in case["crosspoints_2"]]
-    assert hashlib.sha256(out["text"]).hexdigest() == case["alignment_txt_sha256"]
+    res = _case("pruned_60000x50000")
+    assert res["checks"]["pruned"] and res["checks"]["alignment_txt"]
