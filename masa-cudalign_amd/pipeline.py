@@ -5,7 +5,7 @@ executeTraceback() runs after stage 1 (M/libmasa/libmasa.cpp:643-657), with the 
 
     <work>/crosspoints/crosspoint_01.00 .. crosspoint_04.00 (+ crosspoint_03.00.rNN per round of stage 3)
     <work>/special_rows/stage.01.00, stage.02.00, stage.03.00.rNN
-    <work>/status, <work>/alignment.00.txt
+    <work>/status, <work>/alignment.00.bin (alignment_file.py), <work>/alignment.00.txt
 
 The aligner is an MI355Aligner (or anything with its setSequences / alignPartition / matchLastColumn / stage4 /
 unsetSequences); every DP cell of every stage is computed by it.  The sequence modifiers of fasta.py (--trim,
@@ -21,7 +21,7 @@ from .crosspoints import Crosspoint, CrosspointsFile, crosspoint_file
 from .stage1 import stage1
 from .stage2 import stage2
 from .stage3 import stage3
-from . import stage56
+from . import stage56, alignment_file
 
 
 def align(aligner, seq0, seq1, work, alignment_start=AT_ANYWHERE, alignment_end=AT_ANYWHERE, sra_limit=0,
@@ -61,6 +61,8 @@ def align(aligner, seq0, seq1, work, alignment_start=AT_ANYWHERE, alignment_end=
     al = stage56.stage5(seq0, seq1, cp4)
     secs[5] = time.time() - t
     t = time.time()
+    with open(os.path.join(work, "alignment.00.bin"), "wb") as f:          # what stage 5 leaves for stage 6 and the viewers
+        f.write(alignment_file.dumps(al, seq0, seq1))
     text = stage56.stage6_text(al, seq0, seq1)
     with open(os.path.join(work, "alignment.00.txt"), "wb") as f:
         f.write(text)

@@ -199,6 +199,7 @@ def test_sequence_modifiers_through_all_stages(name, pair, flags, mod0, mod1, pk
     for f in sorted(os.listdir(os.path.join(rwork, "crosspoints"))):
         assert filecmp.cmp(os.path.join(rwork, "crosspoints", f), os.path.join(work, "crosspoints", f), shallow=False), f
     assert out["text"] == ref["alignment_txt"]
+    assert open(os.path.join(work, "alignment.00.bin"), "rb").read() == open(os.path.join(rwork, "alignment.00.bin"), "rb").read()
     last_row = "%08X" % (q0.offset1 - (q0.offset0 - 1))      # the native stage 1's completion marker (manager.py)
     for d in sorted(os.listdir(os.path.join(rwork, "special_rows"))):
         p = subprocess.run(["diff", "-rq", "-x", last_row, os.path.join(rwork, "special_rows", d),
@@ -249,6 +250,38 @@ def test_native_stages_continue_a_work_directory_of_masa_core(pkg, oracle, tmp_p
     assert open(os.path.join(wb, "crosspoints", "crosspoint_02.00"), "rb").read() == want2
     stage3(al, s0, s1, wb, sra_limit=limit)
     assert open(os.path.join(wb, "crosspoints", "crosspoint_03.00"), "rb").read() == want3
+
+
+def test_alignment_binary_file(pkg):
+    """alignment.NN.bin (AlignmentBinaryFile.cpp): header, big-endian fields, gap lists as position deltas in 7-bit
+    groups; written and read back"""
+    from masa_cudalign_amd import alignment_file as af, fasta, stage56
+    assert [af._u4c(v) for v in (0, 127, 128, 16383, 16384, 0x0FFFFFFF, 0x10000000, 0xFFFFFFFF)] == [
+        b"\x00", b"\x7f", b"\x81\x00", b"\xff\x7f", b"\x81\x80\x00", b"\xff\xff\xff\x7f", b"\x81\x80\x80\x80\x00",
+        b"\x8f\xff\xff\xff\x7f"]
+    q0 = fasta.parse(b">first one\nACGTACGTAC\n", fasta.SequenceModifiers(trim_start=2, trim_end=9, reverse=True))
+    q1 = fasta.parse(b">second\nACGTTACGTAC\n", fasta.SequenceModifiers(complement=True, clear_n=True))
+    al = stage56.Alignment()
+    al.start, al.end = [2, 1], [9, 11]
+    al.raw_score, al.matches, al.mismatches, al.gap_open, al.gap_extensions = 3, 8, 0, 1, 1
+    al.gaps = ([[5, 1]], [[300, 2], [70000, 129]])
+    data = af.dumps(al, q0, q1)
+    assert data[:6] == b"CGFF\x00\x01"
+    d = af.loads(data)
+    assert [s["description"] for s in d["sequences"]] == ["first one", "second"] and [s["size"] for s in d["sequences"]] == [10, 11]
+    assert d["params"]["method"] == 2 and (d["params"]["match"], d["params"]["mismatch"]) == (1, -3)
+    assert (d["params"]["gap_open"], d["params"]["gap_ext"]) == (-3, -2)
+    assert d["params"]["sequences"][0] == {"index": 0, "reverse": True, "complement": False, "clear_n": False,
+                                           "trim_start": 2, "trim_end": 9}
+    assert d["params"]["sequences"][1]["complement"] and d["params"]["sequences"][1]["clear_n"]
+    assert (d["params"]["sequences"][1]["trim_start"], d["params"]["sequences"][1]["trim_end"]) == (1, 11)
+    r = d["result"]
+    assert (r["raw_score"], r["matches"], r["gap_open"], r["gap_extensions"]) == (3, 8, 1, 1)
+    assert r["start"] == [2, 1] and r["end"] == [9, 11] and r["gaps"] == [[[5, 1]], [[300, 2], [70000, 129]]]
+    with pytest.raises(ValueError):
+        af.loads(b"XXXX" + data[4:])
+    with pytest.raises(ValueError):
+        af.loads(data[:-3])
 
 
 def test_nothing_to_trace_back(pkg, oracle, tmp_path):
