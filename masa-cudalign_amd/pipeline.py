@@ -5,7 +5,7 @@ executeTraceback() runs after stage 1 (M/libmasa/libmasa.cpp:643-657), with the 
 
     <work>/crosspoints/crosspoint_01.00 .. crosspoint_04.00 (+ crosspoint_03.00.rNN per round of stage 3)
     <work>/special_rows/stage.01.00, stage.02.00, stage.03.00.rNN
-    <work>/status, <work>/alignment.00.bin (alignment_file.py), <work>/alignment.00.txt
+    <work>/info, <work>/status, <work>/alignment.00.bin (alignment_file.py), <work>/alignment.00.txt
 
 The aligner is an MI355Aligner (or anything with its setSequences / alignPartition / matchLastColumn / stage4 /
 unsetSequences); every DP cell of every stage is computed by it.  The sequence modifiers of fasta.py (--trim,
@@ -24,6 +24,32 @@ from .stage3 import stage3
 from . import stage56, alignment_file
 
 
+class WorkDirectoryMismatch(RuntimeError):
+    """MASA-Core prints "Sequence mismatch from previous run. Try cleaning work directory (--clean)" and stops"""
+
+
+def check_work_directory(work, seq0, seq1):
+    """Job::initialize (M/common/Job.cpp:68-90): `<work>/info` names the two sequences a work directory belongs to
+    ("seq0=<description>", "seq1=<description>"); a run that finds other names there must not continue from its
+    special rows, status and crosspoints"""
+    os.makedirs(work, exist_ok=True)
+    fn = os.path.join(work, "info")
+    if os.path.exists(fn):
+        prop = {}
+        for line in open(fn, encoding="latin-1"):
+            line = line[:-1]
+            pos = line.find("=")
+            if pos > 0:
+                prop[line[:pos]] = line[pos + 1:]
+        bad = [(k, prop.get(k, ""), s.description) for k, s in (("seq0", seq0), ("seq1", seq1)) if prop.get(k, "") != s.description]
+        if bad:
+            raise WorkDirectoryMismatch("sequence mismatch from a previous run in %s (clean the work directory): %s"
+                                        % (work, "; ".join("%s: %r != %r" % b for b in bad)))
+    else:
+        with open(fn, "w", encoding="latin-1") as f:
+            f.write("seq0=%s\nseq1=%s\n" % (seq0.description, seq1.description))
+
+
 def align(aligner, seq0, seq1, work, alignment_start=AT_ANYWHERE, alignment_end=AT_ANYWHERE, sra_limit=0,
           block_pruning=True, max_partition_size=16, progress=None):
     """seq0, seq1: fasta.Sequence.  Returns {"best", "alignment": stage56.Alignment or None, "text": bytes of
@@ -31,6 +57,7 @@ def align(aligner, seq0, seq1, work, alignment_start=AT_ANYWHERE, alignment_end=
     "seconds": {stage: s}}"""
     # the data the aligner compares: forward or reversed, complemented, N-cleared (fasta.py); --trim only selects the
     # part of the matrix stage 1 sweeps, every coordinate of every stage stays absolute (Sequence.cpp:117-159)
+    check_work_directory(work, seq0, seq1)
     d0, d1 = np.ascontiguousarray(seq0.data()), np.ascontiguousarray(seq1.data())
     bounds = (seq0.offset0 - 1, seq1.offset0 - 1, seq0.offset1, seq1.offset1)
     secs = {}

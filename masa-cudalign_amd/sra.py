@@ -245,7 +245,10 @@ class SpecialRowsPartition:
         self.reload()
 
     def change_path(self, new_path):
-        if self.persistent:
+        if self.persistent and new_path != self.path:
+            if os.path.isdir(new_path):            # left by an earlier run of the same stage in this work directory
+                import shutil
+                shutil.rmtree(new_path)
             os.rename(self.path, new_path)
             self.path = new_path
 

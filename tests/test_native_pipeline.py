@@ -252,6 +252,22 @@ def test_native_stages_continue_a_work_directory_of_masa_core(pkg, oracle, tmp_p
     assert open(os.path.join(wb, "crosspoints", "crosspoint_03.00"), "rb").read() == want3
 
 
+def test_work_directory_belongs_to_its_sequences(pkg, oracle, tmp_path):
+    """<work>/info (Job.cpp:68-90): a second run with other sequences must not continue from the first one's files"""
+    from oracle.aligner_double import SerialBlockAligner
+    from masa_cudalign_amd import fasta, pipeline
+    s0, s1 = pkg.seqgen.related_pair(1500, 1400, cfg=5)
+    q0, q1 = fasta.parse(b">chr1 first\n" + s0.tobytes() + b"\n"), fasta.parse(b">chr2\n" + s1.tobytes() + b"\n")
+    work = str(tmp_path / "work")
+    out = pipeline.align(SerialBlockAligner(128, 128), q0, q1, work, sra_limit=64 * 1024, block_pruning=False)
+    assert open(os.path.join(work, "info")).read() == "seq0=chr1 first\nseq1=chr2\n"
+    again = pipeline.align(SerialBlockAligner(128, 128), q0, q1, work, sra_limit=64 * 1024, block_pruning=False)
+    assert again["text"] == out["text"] and again["stage1"].get("already_done")
+    other = fasta.parse(b">chr3\n" + s1.tobytes() + b"\n")
+    with pytest.raises(pipeline.WorkDirectoryMismatch):
+        pipeline.align(SerialBlockAligner(128, 128), q0, other, work, sra_limit=64 * 1024)
+
+
 def test_alignment_binary_file(pkg):
     """alignment.NN.bin (AlignmentBinaryFile.cpp): header, big-endian fields, gap lists as position deltas in 7-bit
     groups; written and read back"""
