@@ -250,10 +250,10 @@ def read_ref_work(work, log=""):
                     out["pruned_blocks"] = [int(a), int(b)]
     if os.path.exists(os.path.join(work, "status")):
         out["status_txt"] = open(os.path.join(work, "status")).read()
-    for fn in ("alignment.00.txt",):
+    for fn, key in (("alignment.00.txt", "alignment_txt"), ("alignment.00.bin", "alignment_bin")):
         pth = os.path.join(work, fn)
         if os.path.exists(pth):
-            out["alignment_txt"] = open(pth, "rb").read()
+            out[key] = open(pth, "rb").read()
     for st in range(2, 5):
         pth = os.path.join(work, "crosspoints", "crosspoint_%02d.00" % st)
         if os.path.exists(pth):

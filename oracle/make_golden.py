@@ -106,6 +106,7 @@ def main():
             rec["crosspoint_txt"] = ref["crosspoint_txt"]
         if case.get("full"):
             rec["alignment_txt_sha256"] = hashlib.sha256(ref["alignment_txt"]).hexdigest()
+            rec["alignment_bin_sha256"] = hashlib.sha256(ref["alignment_bin"]).hexdigest()   # AlignmentBinaryFile ("CGFF")
             rec["crosspoints_2"] = ref.get("crosspoints_2")
             # stage 3 -> stage 4 (Myers-Miller refinement): the input list, and the output file's digest
             rec["crosspoints_3"] = ref.get("crosspoints_3")

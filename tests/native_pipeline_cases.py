@@ -50,6 +50,8 @@ def run(case_name):
     if exact:
         checks["crosspoints_2"] = cp2 == want2
         checks["alignment_txt"] = hashlib.sha256(out["text"]).hexdigest() == case["alignment_txt_sha256"]
+        checks["alignment_bin"] = hashlib.sha256(open(os.path.join(work, "alignment.00.bin"), "rb").read()).hexdigest() == \
+            case["alignment_bin_sha256"]
     else:                      # another special-row spacing may pick another, equally optimal path
         checks["start_and_end"] = bool(cp2) and cp2[0] == want2[0] and cp2[-1] == want2[-1]
     if pkw.get("block_pruning"):

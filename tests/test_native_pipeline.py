@@ -59,6 +59,7 @@ def test_pipeline_reproduces_the_fixture(case, pkg, oracle, tmp_path):
     assert hashlib.sha256(open(crosspoint_file(work, 4), "rb").read()).hexdigest() == case["crosspoints_4"]["file_sha256"]
     assert hashlib.sha256(out["text"]).hexdigest() == case["alignment_txt_sha256"]
     assert open(os.path.join(work, "alignment.00.txt"), "rb").read() == out["text"]
+    assert hashlib.sha256(open(os.path.join(work, "alignment.00.bin"), "rb").read()).hexdigest() == case["alignment_bin_sha256"]
     assert out["alignment"].raw_score == case["best"][2]
 
 
