@@ -12,6 +12,10 @@ Layout ("CGFF", version 0.1; integers big-endian, strings length-prefixed, field
                                [5 per sequence: start, end, #gaps, per gap: (position - previous position, length) as
                                   7-bit groups, most significant first, high bit = "more follows"] 0
 
+A gap run that a partition border of stage 5 cuts in two is stored as two entries with the same position; the reference
+sorts its gap list with std::sort on the position alone (Alignment.cpp:112-124), so the order of such twins is whatever
+the C++ library makes of it.  Readers, MASA-Core's included, treat them alike; `canonical()` orders them for comparisons.
+
 The parameters are MASA-Core's defaults (M/libmasa/libmasa.cpp:772-777: method LOCAL whatever the edges, penalties stored
 NEGATED: -3, -2)."""
 import struct
@@ -183,3 +187,12 @@ def loads(data):
         else:
             raise ValueError("unknown result field %d" % f)
     return {"sequences": seqs, "params": params, "result": res}
+
+
+def canonical(parsed):
+    """`loads()` output with gap entries of equal position in a fixed order (by length)"""
+    out = dict(parsed)
+    res = dict(parsed["result"])
+    res["gaps"] = [sorted([list(g) for g in gaps]) for gaps in parsed["result"]["gaps"]]
+    out["result"] = res
+    return out

@@ -107,6 +107,8 @@ def main():
         if case.get("full"):
             rec["alignment_txt_sha256"] = hashlib.sha256(ref["alignment_txt"]).hexdigest()
             rec["alignment_bin_sha256"] = hashlib.sha256(ref["alignment_bin"]).hexdigest()   # AlignmentBinaryFile ("CGFF")
+            rec["alignment_bin_hex"] = ref["alignment_bin"].hex()      # 1-2 KB: gap entries with equal positions come out of
+            #                                                            the reference's std::sort in a library-defined order
             rec["crosspoints_2"] = ref.get("crosspoints_2")
             # stage 3 -> stage 4 (Myers-Miller refinement): the input list, and the output file's digest
             rec["crosspoints_3"] = ref.get("crosspoints_3")
