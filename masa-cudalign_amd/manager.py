@@ -138,22 +138,80 @@ class ReversedCellsReader:
 
 
 class BestScoreList:
-    """limit-1 behaviour of M/common/BestScoreList.cpp:129-195 with the order of BestScoreList.hpp:30-38:
-    score desc, then i asc, then j asc; scores below min_score are ignored."""
+    """M/common/BestScoreList.cpp:45-195 with the order of BestScoreList.hpp:30-38 (score desc, then i asc, then j asc).
+    Up to `limit` end points of DIFFERENT alignments (--max-alignments): a candidate that lies in the shadow of a better
+    one -- reachable from it by a diagonal run and gaps whose expected cost explains the score difference (isDerived,
+    :67-107) -- or that scores under a quarter of the best (isAllowed, :109-117) is not kept, and a new entry evicts the
+    entries it shadows.  With limit 1 this is the canonical best cell: (max score, min i, min j).
+    seq0_len / seq1_len: the extent of the matrix stage 1 sweeps (sw_stage1.cpp:285-286, :330)."""
 
-    def __init__(self, min_score):
-        self.min_score = min_score
-        self.best = None
+    MATCH, MISMATCH, GAP_EXT_ = 1, -3, 2
+
+    def __init__(self, min_score, limit=1, seq0_len=0, seq1_len=0):
+        self.min_score, self.limit = min_score, max(int(limit), 1)
+        self.seq0_len, self.seq1_len = seq0_len, seq1_len
+        self.entries = []               # (i, j, score), best first
+
+    @staticmethod
+    def _key(e):
+        return (-e[2], e[0], e[1])
+
+    @property
+    def best(self):
+        return self.entries[0] if self.entries else None
+
+    def _derived(self, best, cand):
+        """isDerived(best, cand): is `cand` just another cell of the alignment that ends in `best`?"""
+        diff_z, diff_x, diff_y = cand[2] - best[2], cand[1] - best[1], cand[0] - best[0]
+        if diff_z >= 0:
+            return False
+        ax, ay = abs(diff_x), abs(diff_y)
+        if self.min_score >= 0 and best[2] > (ax + ay) // self.GAP_EXT_:
+            return True
+        if self.min_score < 0 and ax + ay > min(self.seq0_len, self.seq1_len):
+            return True
+        same_side = (diff_x <= 0 and diff_y <= 0) or (diff_x >= 0 and diff_y >= 0)
+        gaps = abs(ax - ay) if same_side else ax + ay
+        diagonal = min(ax, ay)
+        f32 = np.float32                                     # the reference computes these bounds in single precision
+        z_min = int((f32(self.MISMATCH) * (f32(1) - f32(0.25)) + f32(self.MATCH) * f32(0.25)) * f32(diagonal))
+        z_max = self.MATCH * diagonal
+        g_diff = self.GAP_EXT_ * gaps
+        return bool(f32(diff_z) >= f32(z_min) - f32(g_diff) * f32(2.0) and f32(diff_z) <= f32(z_max) - f32(g_diff) / f32(2.0))
+
+    @staticmethod
+    def _allowed(best, cand):
+        if best[2] > 0 and cand[2] < 0.25 * best[2]:
+            return False
+        if best[2] < 0 and cand[2] < 1.10 * best[2]:
+            return False
+        return True
 
     def add(self, i, j, score):
+        """_add (:129-195)"""
         if score < self.min_score:
             return
-        c = (-score, i, j)
-        if self.best is None or c < (-self.best[2], self.best[0], self.best[1]):
-            self.best = (i, j, score)
+        reg = (int(i), int(j), int(score))
+        e = self.entries
+        if len(e) == self.limit and e[-1][2] > reg[2]:
+            return
+        if e and not self._allowed(e[0], reg):
+            return
+        if reg in e:
+            return
+        if any(self._derived(it, reg) for it in e):
+            return
+        e[:] = [it for it in e if not (self._derived(reg, it) or not self._allowed(reg, it))]
+        e.append(reg)
+        e.sort(key=self._key)
+        if len(e) > self.limit:
+            e.pop()
 
     def getBestScore(self):
-        return self.best if self.best is not None else (-1, -1, -INF)
+        return self.entries[0] if self.entries else (-1, -1, -INF)
+
+    def all(self):
+        return list(self.entries)
 
 
 def initial_best_score(alignment_start, alignment_end):
@@ -177,7 +235,7 @@ class Stage1Manager:
     def __init__(self, partition, alignment_start=AT_ANYWHERE, alignment_end=AT_ANYWHERE,
                  special_row_interval=0, keep_last_row=False, keep_last_column=False,
                  first_row_reader=None, first_column_reader=None, seq0_offset=0, seq1_offset=0,
-                 super_partition=None, block_pruning=False, sra_partition=None, status=None):
+                 super_partition=None, block_pruning=False, sra_partition=None, status=None, max_alignments=1):
         self.partition = partition
         self.super_partition = super_partition or partition
         self.seq0_offset, self.seq1_offset = seq0_offset, seq1_offset
@@ -198,7 +256,9 @@ class Stage1Manager:
             first_column_reader = first_column_reader or fc
         self.first_row_reader, self.first_column_reader = first_row_reader, first_column_reader
         self.best_location = alignment_end
-        self.best_list = BestScoreList(initial_best_score(alignment_start, alignment_end))
+        sup = super_partition or partition
+        self.best_list = BestScoreList(initial_best_score(alignment_start, alignment_end), max_alignments,
+                                       sup.i1 - sup.i0, sup.j1 - sup.j0)
         self.special_row_interval = special_row_interval
         self.keep_last_row, self.keep_last_column = keep_last_row, keep_last_column
         # sw_stage1.cpp:219-225: pruning only when the alignment may end anywhere

@@ -51,49 +51,61 @@ def check_work_directory(work, seq0, seq1):
 
 
 def align(aligner, seq0, seq1, work, alignment_start=AT_ANYWHERE, alignment_end=AT_ANYWHERE, sra_limit=0,
-          block_pruning=True, max_partition_size=16, progress=None):
+          block_pruning=True, max_partition_size=16, progress=None, max_alignments=1):
     """seq0, seq1: fasta.Sequence.  Returns {"best", "alignment": stage56.Alignment or None, "text": bytes of
     alignment.00.txt or None when nothing scored above the floor, "crosspoints": {2: n, 3: n, 4: n},
-    "seconds": {stage: s}}"""
+    "seconds": {stage: s}}; with max_alignments > 1 also "alignments": one such record per end point stage 1 kept
+    (alignment.NN.txt, crosspoint_0S.NN, special_rows/stage.0S.NN: executeTraceback, libmasa.cpp:643-657)"""
+    check_work_directory(work, seq0, seq1)
     # the data the aligner compares: forward or reversed, complemented, N-cleared (fasta.py); --trim only selects the
     # part of the matrix stage 1 sweeps, every coordinate of every stage stays absolute (Sequence.cpp:117-159)
-    check_work_directory(work, seq0, seq1)
     d0, d1 = np.ascontiguousarray(seq0.data()), np.ascontiguousarray(seq1.data())
     bounds = (seq0.offset0 - 1, seq1.offset0 - 1, seq0.offset1, seq1.offset1)
     secs = {}
     t = time.time()
     r1 = stage1(aligner, d0, d1, work, alignment_start=alignment_start, alignment_end=alignment_end, sra_limit=sra_limit,
-                block_pruning=block_pruning, bounds=bounds, progress=progress)
+                block_pruning=block_pruning, bounds=bounds, progress=progress, max_alignments=max_alignments)
     secs[1] = time.time() - t
-    out = {"best": r1["best"], "alignment": None, "text": None, "crosspoints": {}, "seconds": secs, "stage1": r1}
+    out = {"best": r1["best"], "alignment": None, "text": None, "crosspoints": {}, "seconds": secs, "stage1": r1,
+           "alignments": []}
     if r1["best"] is None or r1["best"][2] <= -INF or r1["best"][0] < 0:
         return out                                        # an empty best-score list: MASA-Core runs no traceback either
+    for ident in range(max(len(r1.get("bests", [])), 1)):
+        rec = _traceback(aligner, seq0, seq1, d0, d1, work, ident, alignment_start, sra_limit, max_partition_size, bounds, secs)
+        out["alignments"].append(rec)
+    out.update(out["alignments"][0])
+    return out
+
+
+def _traceback(aligner, seq0, seq1, d0, d1, work, ident, alignment_start, sra_limit, max_partition_size, bounds, secs):
+    """stages 2-6 for the alignment that ends in crosspoint_01.<ident>"""
+    def clock(stage, t0):
+        secs[stage] = secs.get(stage, 0.0) + time.time() - t0
     t = time.time()
-    r2 = stage2(aligner, d0, d1, work, alignment_start=alignment_start, sra_limit=sra_limit, bounds=bounds)
-    secs[2] = time.time() - t
+    r2 = stage2(aligner, d0, d1, work, alignment_start=alignment_start, sra_limit=sra_limit, ident=ident, bounds=bounds)
+    clock(2, t)
     t = time.time()
-    r3 = stage3(aligner, d0, d1, work, sra_limit=sra_limit)
-    secs[3] = time.time() - t
+    r3 = stage3(aligner, d0, d1, work, sra_limit=sra_limit, ident=ident)
+    clock(3, t)
     t = time.time()
     aligner.setSequences(d0, d1)
     try:
         cp4, st4 = aligner.stage4(r3["crosspoints"], max_partition_size)
     finally:
         aligner.unsetSequences()
-    f4 = CrosspointsFile(crosspoint_file(work, 4, 0))
+    f4 = CrosspointsFile(crosspoint_file(work, 4, ident))
     f4.extend(Crosspoint(i, j, s, ty) for (ty, i, j, s) in cp4)
     f4.save()
-    secs[4] = time.time() - t
+    clock(4, t)
     t = time.time()
     al = stage56.stage5(seq0, seq1, cp4)
-    secs[5] = time.time() - t
+    clock(5, t)
     t = time.time()
-    with open(os.path.join(work, "alignment.00.bin"), "wb") as f:          # what stage 5 leaves for stage 6 and the viewers
+    with open(os.path.join(work, "alignment.%02d.bin" % ident), "wb") as f:   # what stage 5 leaves for stage 6 and the viewers
         f.write(alignment_file.dumps(al, seq0, seq1))
     text = stage56.stage6_text(al, seq0, seq1)
-    with open(os.path.join(work, "alignment.00.txt"), "wb") as f:
+    with open(os.path.join(work, "alignment.%02d.txt" % ident), "wb") as f:
         f.write(text)
-    secs[6] = time.time() - t
-    out.update(alignment=al, text=text, crosspoints={2: len(r2["crosspoints"]), 3: len(r3["crosspoints"]), 4: len(cp4)},
-               stage2=r2, stage3=r3, stage4=st4)
-    return out
+    clock(6, t)
+    return dict(alignment=al, text=text, crosspoints={2: len(r2["crosspoints"]), 3: len(r3["crosspoints"]), 4: len(cp4)},
+                stage2=r2, stage3=r3, stage4=st4)

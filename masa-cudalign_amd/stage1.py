@@ -54,8 +54,22 @@ def _start_progress_log(aligner, mgr, stream, interval, t0):
     return stop
 
 
+def _crosspoints_on_disk(work):
+    """the end points a finished stage 1 left (crosspoint_01.00, .01, ...)"""
+    out, k = [], 0
+    while os.path.exists(sra_mod.crosspoint_path(work, 1, k)):
+        tok = open(sra_mod.crosspoint_path(work, 1, k)).read().split()
+        if len(tok) < 3:
+            break
+        _t, i, j, sc = (int(x) for x in tok[1].split(","))
+        out.append((i, j, sc))
+        k += 1
+    return out
+
+
 def stage1(aligner, seq0, seq1, work, alignment_start=AT_ANYWHERE, alignment_end=AT_ANYWHERE, sra_limit=0,
-           block_pruning=True, manager_class=Stage1Manager, bounds=None, progress=None, progress_interval=2.0):
+           block_pruning=True, manager_class=Stage1Manager, bounds=None, progress=None, progress_interval=2.0,
+           max_alignments=1):
     """Runs (or resumes) stage 1 of seq0 x seq1 in work directory `work`.  `aligner` is an MI355Aligner; create it
     with a fixed strip height (rows_per_lane) when the area must be resumable or shared with CUDAlign: special rows
     sit on multiples of the strip height (1024 or 2048 rows give CUDAlign's 8192-row spacing).
@@ -65,7 +79,9 @@ def stage1(aligner, seq0, seq1, work, alignment_start=AT_ANYWHERE, alignment_end
     `progress`: a text stream (sys.stderr) that gets MASA-Core's progress line every `progress_interval` seconds while
     the aligner runs -- "(0h00m02s) best:(i,j,score) PROGRESS: d/D strips" (logStatus, sw_stage1.cpp:112-128; the status
     file itself is saved with every completed special row, not by this timer).
-    Returns {"best": (i, j, score) in 1-based DP coordinates, "resumed_from": row or None, "seconds", "gcups", ...}."""
+    `max_alignments` > 1 (--max-alignments): the best-score list keeps that many end points of different alignments
+    (BestScoreList), one crosspoint_01.NN each; candidates are what the aligner dispatches (one best cell per strip).
+    Returns {"best": (i, j, score) in 1-based DP coordinates, "bests": the whole list, "resumed_from": row or None, "seconds", "gcups", ...}."""
     m, n = len(seq0), len(seq1)
     bi0, bj0, bi1, bj1 = bounds if bounds is not None else (0, 0, m, n)
     if not (0 <= bi0 < bi1 <= m and 0 <= bj0 < bj1 <= n):
@@ -80,7 +96,7 @@ def stage1(aligner, seq0, seq1, work, alignment_start=AT_ANYWHERE, alignment_end
         last = part_sra.last_row_id()
         if last == bi1 and status.loaded:
             # "Stage 1 was already executed" (sw_stage1.cpp:212-214)
-            return {"best": status.best, "resumed_from": bi1, "seconds": 0.0, "gcups": 0.0, "already_done": True,
+            return {"best": status.best, "bests": _crosspoints_on_disk(work), "resumed_from": bi1, "seconds": 0.0, "gcups": 0.0, "already_done": True,
                     "special_rows": [r for r in part_sra.rows]}
         if last != bi0:
             i0, row = part_sra.continue_from_last_row()
@@ -101,7 +117,8 @@ def stage1(aligner, seq0, seq1, work, alignment_start=AT_ANYWHERE, alignment_end
     mgr = manager_class(part, alignment_start=alignment_start, alignment_end=alignment_end,
                         special_row_interval=interval, first_row_reader=fr, first_column_reader=fc,
                         super_partition=sup, block_pruning=block_pruning,
-                        sra_partition=part_sra, status=status, seq0_offset=bi0, seq1_offset=bj0)
+                        sra_partition=part_sra, status=status, seq0_offset=bi0, seq1_offset=bj0,
+                        **({"max_alignments": max_alignments} if max_alignments != 1 else {}))
     if status.loaded and status.best is not None and status.best[0] >= 0:
         mgr.best_list.add(*status.best)            # Status::load -> bestScoreList->add (Status.cpp:60-64)
     status.stage = 1
@@ -151,11 +168,12 @@ def stage1(aligner, seq0, seq1, work, alignment_start=AT_ANYWHERE, alignment_end
     if part_sra is not None:
         status.last_special_row = part_sra.last_row_id()
     status.save(best)
-    if best[0] >= 0 and best[2] > -sra_mod.INF:
-        sra_mod.write_crosspoint(sra_mod.crosspoint_path(work, 1, 0), best)
+    bests = mgr.best_list.all() if hasattr(mgr.best_list, "all") else ([tuple(best)] if best[0] >= 0 else [])
+    for k, b in enumerate(bests):                   # sw_stage1.cpp:481-492: one file per entry of the list
+        sra_mod.write_crosspoint(sra_mod.crosspoint_path(work, 1, k), b)
     # else: an empty best-score list -- MASA-Core writes no crosspoint file and runs no traceback (sw_stage1.cpp:481-492: one file per entry of the list)
     st = aligner.getStatistics()
-    return {"best": tuple(best), "resumed_from": resumed_from, "seconds": dt,
+    return {"best": tuple(best), "bests": [tuple(b) for b in bests], "resumed_from": resumed_from, "seconds": dt,
             "gcups": float(bi1 - i0) * (bj1 - bj0) / dt / 1e9 if dt > 0 else 0.0, "strip_rows": st["strip_rows"],
             "kernel_ms": st["kernel_ms"], "pruned_cells": st["pruned_cells"], "located_from_value": located,
             "special_rows": list(part_sra.rows) if part_sra is not None else []}

@@ -260,6 +260,71 @@ def test_native_stages_continue_a_work_directory_of_masa_core(pkg, oracle, tmp_p
     assert open(os.path.join(wb, "crosspoints", "crosspoint_03.00"), "rb").read() == want3
 
 
+def _three_segments(pkg, seed=5):
+    g = pkg.seqgen
+    a, b, c = g.random_dna(100 + seed, 2000), g.random_dna(200 + seed, 1500), g.random_dna(300 + seed, 900)
+    s0 = np.concatenate([a, g.random_dna(400 + seed, 500), b, g.random_dna(401 + seed, 300), c])
+    s1 = np.concatenate([g.mutate_dna(b, 500 + seed, inversion=0.0), g.random_dna(402 + seed, 400),
+                         g.mutate_dna(c, 501 + seed, inversion=0.0), g.random_dna(403 + seed, 200),
+                         g.mutate_dna(a, 502 + seed, inversion=0.0)])
+    return s0, s1
+
+
+@pytest.mark.parametrize("name,pair,count", [
+    ("shuffled_segments_2", _three_segments, 2), ("shuffled_segments_5", _three_segments, 5),
+    ("unrelated_4", lambda pkg: pkg.seqgen.unrelated_pair(4000, 4000, cfg=8), 4)])
+def test_several_alignments(name, pair, count, pkg, oracle, tmp_path):
+    """--max-alignments=N: the best-score list keeps end points of different alignments (BestScoreList: shadowed and
+    weak candidates dropped, a better newcomer evicts what it shadows), stage 1 writes one crosspoint_01.NN each and the
+    traceback runs once per end point -- same crosspoint files and the same alignment.NN.txt as MASA-Core"""
+    if not oracle.have_ref():
+        pytest.skip("oracle/_ref not built (needs /root/reference)")
+    from oracle.aligner_double import SerialBlockAligner
+    from masa_cudalign_amd import fasta, pipeline
+    s0, s1 = pair(pkg)
+    limit = 150 * 1024
+    refdir = tmp_path / "ref"
+    refdir.mkdir()
+    oracle.run_ref(s0, s1, ["--disk-size=%d" % limit, "--block=128,128", "--no-block-pruning", "--max-alignments=%d" % count],
+                   workdir=str(refdir), timeout=600)
+    rwork = str(refdir / "work")
+    q0, q1 = _fasta(pkg, s0, s1)
+    work = str(tmp_path / "native")
+    out = pipeline.align(SerialBlockAligner(128, 128), q0, q1, work, sra_limit=limit, block_pruning=False, max_alignments=count)
+    want = sorted(os.listdir(os.path.join(rwork, "crosspoints")))
+    assert sorted(os.listdir(os.path.join(work, "crosspoints"))) == want
+    for f in want:
+        assert filecmp.cmp(os.path.join(rwork, "crosspoints", f), os.path.join(work, "crosspoints", f), shallow=False), f
+    texts = sorted(f for f in os.listdir(rwork) if f.startswith("alignment.") and f.endswith(".txt"))
+    assert len(texts) == len(out["alignments"]) == len(out["stage1"]["bests"]) >= (2 if count > 1 else 1)
+    for f in texts:
+        assert filecmp.cmp(os.path.join(rwork, f), os.path.join(work, f), shallow=False), f
+    scores = [b[2] for b in out["stage1"]["bests"]]
+    assert scores == sorted(scores, reverse=True) and len(scores) <= count
+
+
+def test_best_score_list_rules(pkg):
+    from masa_cudalign_amd.manager import BestScoreList
+    b = BestScoreList(0, limit=3, seq0_len=10000, seq1_len=10000)
+    b.add(500, 500, 400)
+    b.add(490, 490, 390)            # ten cells up the same diagonal, ten points less: the same alignment
+    assert b.all() == [(500, 500, 400)]
+    b.add(3000, 7000, 90)           # under a quarter of the best: not worth a traceback
+    assert b.all() == [(500, 500, 400)]
+    b.add(3000, 7000, 300)
+    b.add(8000, 2000, 300)          # ties order by row, then column
+    assert b.all() == [(500, 500, 400), (3000, 7000, 300), (8000, 2000, 300)]
+    b.add(9000, 9000, 250)          # list full, worse than its last entry
+    assert len(b.all()) == 3 and b.getBestScore() == (500, 500, 400)
+    b.add(510, 510, 410)            # a better end of the first alignment evicts the one it shadows
+    assert b.all()[0] == (510, 510, 410) and (500, 500, 400) not in b.all()
+    one = BestScoreList(0)
+    for cell in ((7, 9, 20), (5, 9, 20), (5, 3, 20), (6, 1, 19)):
+        one.add(*cell)
+    assert one.all() == [(5, 3, 20)]                   # limit 1: max score, min i, min j
+    assert BestScoreList(5).getBestScore()[2] < -10 ** 8 and BestScoreList(5).best is None
+
+
 def test_work_directory_belongs_to_its_sequences(pkg, oracle, tmp_path):
     """<work>/info (Job.cpp:68-90): a second run with other sequences must not continue from the first one's files"""
     from oracle.aligner_double import SerialBlockAligner

@@ -6,6 +6,7 @@ MI355X) behind the handful of MASA-CUDAlign options that concern the path -- not
       --disk-size=N[KMG]        Special Rows Area budget (default: 8192-row spacing; the traceback needs special rows)
       --trim=I0,I1,J0,J1  --reverse=1|2|both  --complement=1|2|both  --reverse-complement=1|2|both  --clear-n
       --alignment-edges=XY      X start, Y end: * anywhere (local), 1 / 2 on that sequence's edge, 3 on either, + on both (global)
+      --max-alignments=N        trace back up to N different alignments (alignment.00.txt .. alignment.NN.txt)
       --no-block-pruning  --gpu=ID  --stage-1 (best score only)
 
 Prints one JSON line (best score, crosspoints per stage, seconds per stage) and leaves alignment.00.txt in the work
@@ -32,7 +33,7 @@ def main(argv):
     from masa_cudalign_amd import fasta, pipeline, stage1
     edge = {"*": pkg.AT_ANYWHERE, "1": pkg.AT_SEQUENCE_1, "2": pkg.AT_SEQUENCE_2, "3": pkg.AT_SEQUENCE_1_OR_2,
             "+": pkg.AT_SEQUENCE_1_AND_2}
-    work, limit, device, prune, only1, edges = "./work.tmp", None, 0, True, False, "**"
+    work, limit, device, prune, only1, edges, count = "./work.tmp", None, 0, True, False, "**", 1
     trim, rev, comp, clear_n = [0, 0, 0, 0], [False, False], [False, False], False
     files = []
     for a in argv:
@@ -52,6 +53,8 @@ def main(argv):
             clear_n = True
         elif a.startswith("--alignment-edges="):
             edges = a[18:]
+        elif a.startswith("--max-alignments="):
+            count = int(a[17:])
         elif a == "--no-block-pruning":
             prune = False
         elif a.startswith("--gpu="):
@@ -74,14 +77,14 @@ def main(argv):
             bounds = (seqs[0].offset0 - 1, seqs[1].offset0 - 1, seqs[0].offset1, seqs[1].offset1)
             r = stage1.stage1(al, seqs[0].data(), seqs[1].data(), work, alignment_start=edge[edges[0]],
                               alignment_end=edge[edges[1]], sra_limit=limit, block_pruning=prune, bounds=bounds,
-                              progress=sys.stderr)
+                              progress=sys.stderr, max_alignments=count)
             res = {"best": list(r["best"]), "seconds": {"1": r["seconds"]}, "gcups": r["gcups"]}
         else:
             out = pipeline.align(al, seqs[0], seqs[1], work, alignment_start=edge[edges[0]], alignment_end=edge[edges[1]],
-                                 sra_limit=limit, block_pruning=prune, progress=sys.stderr)
+                                 sra_limit=limit, block_pruning=prune, progress=sys.stderr, max_alignments=count)
             res = {"best": list(out["best"]), "seconds": {str(k): v for k, v in out["seconds"].items()},
                    "crosspoints": {str(k): v for k, v in out["crosspoints"].items()},
-                   "alignment": os.path.join(work, "alignment.00.txt") if out["text"] else None}
+                   "alignments": [os.path.join(work, "alignment.%02d.txt" % k) for k in range(len(out["alignments"]))]}
     finally:
         al.close()
     print(json.dumps(res))
