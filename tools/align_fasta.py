@@ -3,7 +3,7 @@ MI355X) behind the handful of MASA-CUDAlign options that concern the path -- not
 
     python tools/align_fasta.py [options] seq0.fasta seq1.fasta
       --work-dir=DIR            work directory in MASA-Core's layout (default ./work.tmp); a killed stage 1 resumes from it
-      --disk-size=N[KMG]        Special Rows Area budget (default: 8192-row spacing; the traceback needs special rows)
+      --disk-size=N[KMG]        Special Rows Area budget (default: 8192-row spacing, at most 4 GiB; the traceback needs special rows)
       --trim=I0,I1,J0,J1  --reverse=1|2|both  --complement=1|2|both  --reverse-complement=1|2|both  --clear-n
       --alignment-edges=XY      X start, Y end: * anywhere (local), 1 / 2 on that sequence's edge, 3 on either, + on both (global)
       --max-alignments=N        trace back up to N different alignments (alignment.00.txt .. alignment.NN.txt)
@@ -70,7 +70,7 @@ def main(argv):
     seqs = [fasta.load(files[k], fasta.SequenceModifiers(clear_n=clear_n, reverse=rev[k], complement=comp[k],
                                                          trim_start=trim[2 * k], trim_end=trim[2 * k + 1])) for k in (0, 1)]
     if limit is None:
-        limit = (len(seqs[0]) // 8192 + 2) * (len(seqs[1]) + 1) * 8
+        limit = min((len(seqs[0]) // 8192 + 2) * (len(seqs[1]) + 1) * 8, 4 << 30)
     al = pkg.MI355Aligner(device=device)
     try:
         if only1:

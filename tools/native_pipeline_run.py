@@ -23,8 +23,9 @@ from masa_cudalign_amd import fasta, pipeline  # noqa: E402
 
 def main():
     m, n = int(sys.argv[1]), int(sys.argv[2])
-    limit = int(float(sys.argv[3])) if len(sys.argv) > 3 else max(200 * 1024, (m // 8192 + 1) * n * 8)
-    outfn = sys.argv[4] if len(sys.argv) > 4 else None
+    # default budget: a special row every 8192 rows, but no more than 4 GiB of them on disk
+    limit = int(float(sys.argv[3])) if len(sys.argv) > 3 and sys.argv[3] != "-" else min(max(200 * 1024, (m // 8192 + 1) * n * 8), 4 << 30)
+    outfn = sys.argv[4] if len(sys.argv) > 4 and sys.argv[4] != "-" else None
     cfg = int(sys.argv[5]) if len(sys.argv) > 5 else 2
     s0, s1 = pkg.seqgen.related_pair(m, n, cfg=cfg)
     q0 = fasta.Sequence(">s0", s0, fasta.SequenceModifiers())
