@@ -70,7 +70,10 @@ def _process_partition(mgr, area, prev_part, c0, c1, len_v, len_h, reverse, out)
 def _reduce_partitions(mgr, prev, out, seq_v, seq_h, area_prev, area, reverse):
     """reduce_partitions (:210-262): `prev` runs from the alignment's start to its end in this round's orientation"""
     len_v, len_h = len(seq_v), len(seq_h)
-    mgr.setSequences(seq_v, seq_h, prev[0].i, prev[0].j, prev[-1].i, prev[-1].j)
+    # (an alignment of one crosspoint, or one that runs along a border, spans no cells: nothing to hand to the aligner)
+    spans = prev[-1].i > prev[0].i and prev[-1].j > prev[0].j
+    if spans:
+        mgr.setSequences(seq_v, seq_h, prev[0].i, prev[0].j, prev[-1].i, prev[-1].j)
     sweeps = 0
     try:
         for c0, c1 in zip(prev, prev[1:]):
@@ -85,7 +88,8 @@ def _reduce_partitions(mgr, prev, out, seq_v, seq_h, area_prev, area, reverse):
             # else: a partition crossed by one gap run, nothing to refine
         out.write(prev[-1])
     finally:
-        mgr.unsetSequences()
+        if spans:
+            mgr.unsetSequences()
     out.close()
     return sweeps
 
