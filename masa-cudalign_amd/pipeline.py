@@ -51,7 +51,7 @@ def check_work_directory(work, seq0, seq1):
 
 
 def align(aligner, seq0, seq1, work, alignment_start=AT_ANYWHERE, alignment_end=AT_ANYWHERE, sra_limit=0,
-          block_pruning=True, max_partition_size=16, progress=None, max_alignments=1):
+          block_pruning=True, max_partition_size=16, progress=None, max_alignments=1, ram_limit=0):
     """seq0, seq1: fasta.Sequence.  Returns {"best", "alignment": stage56.Alignment or None, "text": bytes of
     alignment.00.txt or None when nothing scored above the floor, "crosspoints": {2: n, 3: n, 4: n},
     "seconds": {stage: s}}; with max_alignments > 1 also "alignments": one such record per end point stage 1 kept
@@ -62,30 +62,35 @@ def align(aligner, seq0, seq1, work, alignment_start=AT_ANYWHERE, alignment_end=
     d0, d1 = np.ascontiguousarray(seq0.data()), np.ascontiguousarray(seq1.data())
     bounds = (seq0.offset0 - 1, seq1.offset0 - 1, seq0.offset1, seq1.offset1)
     secs = {}
+    areas = {}                     # Job's cache of special-rows areas: rows kept in memory live here between the stages
     t = time.time()
     r1 = stage1(aligner, d0, d1, work, alignment_start=alignment_start, alignment_end=alignment_end, sra_limit=sra_limit,
-                block_pruning=block_pruning, bounds=bounds, progress=progress, max_alignments=max_alignments)
+                block_pruning=block_pruning, bounds=bounds, progress=progress, max_alignments=max_alignments,
+                ram_limit=ram_limit, areas=areas)
     secs[1] = time.time() - t
     out = {"best": r1["best"], "alignment": None, "text": None, "crosspoints": {}, "seconds": secs, "stage1": r1,
            "alignments": []}
     if r1["best"] is None or r1["best"][2] <= -INF or r1["best"][0] < 0:
         return out                                        # an empty best-score list: MASA-Core runs no traceback either
     for ident in range(max(len(r1.get("bests", [])), 1)):
-        rec = _traceback(aligner, seq0, seq1, d0, d1, work, ident, alignment_start, sra_limit, max_partition_size, bounds, secs)
+        rec = _traceback(aligner, seq0, seq1, d0, d1, work, ident, alignment_start, sra_limit, max_partition_size, bounds, secs,
+                         ram_limit, areas)
         out["alignments"].append(rec)
     out.update(out["alignments"][0])
     return out
 
 
-def _traceback(aligner, seq0, seq1, d0, d1, work, ident, alignment_start, sra_limit, max_partition_size, bounds, secs):
+def _traceback(aligner, seq0, seq1, d0, d1, work, ident, alignment_start, sra_limit, max_partition_size, bounds, secs,
+               ram_limit=0, areas=None):
     """stages 2-6 for the alignment that ends in crosspoint_01.<ident>"""
     def clock(stage, t0):
         secs[stage] = secs.get(stage, 0.0) + time.time() - t0
     t = time.time()
-    r2 = stage2(aligner, d0, d1, work, alignment_start=alignment_start, sra_limit=sra_limit, ident=ident, bounds=bounds)
+    r2 = stage2(aligner, d0, d1, work, alignment_start=alignment_start, sra_limit=sra_limit, ident=ident, bounds=bounds,
+                ram_limit=ram_limit, areas=areas)
     clock(2, t)
     t = time.time()
-    r3 = stage3(aligner, d0, d1, work, sra_limit=sra_limit, ident=ident)
+    r3 = stage3(aligner, d0, d1, work, sra_limit=sra_limit, ident=ident, ram_limit=ram_limit, areas=areas)
     clock(3, t)
     t = time.time()
     aligner.setSequences(d0, d1)

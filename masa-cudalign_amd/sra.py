@@ -63,6 +63,20 @@ class _OpenRow:
         os.replace(self.tmp, self.final)
 
 
+class _OpenRamRow:
+    """SpecialRowRAM.cpp: a row kept in memory for the life of the area object (the same process's later stages)"""
+
+    def __init__(self, rowid, width_cells):
+        self.id = rowid
+        self.cells = np.empty((width_cells, 2), dtype=np.int32)
+        self.offset = 0
+
+    def write(self, cells):
+        a = np.asarray(cells, dtype=np.int32).reshape(-1, 2)
+        self.cells[self.offset:self.offset + a.shape[0]] = a
+        self.offset += a.shape[0]
+
+
 class SpecialRowReader:
     """One special row opened for the traceback (SpecialRow.cpp:90-147): seeked to a cell count, it is read BACKWARDS
     from there, every read returning its cells in reversed order -- the order in which the next stage, which sweeps
@@ -89,6 +103,9 @@ class SpecialRowReader:
             reader.seek(offset)
             reader.read(tmp, length)
             return tmp
+        ram = self.partition._ram.get(self.id)
+        if ram is not None:
+            return ram[offset:offset + length]
         fn = os.path.join(self.partition.path, "%08X" % self.id)
         a = np.fromfile(fn, dtype=np.int32, count=2 * length, offset=CELL_BYTES * offset).reshape(-1, 2)
         if a.shape[0] != length:
@@ -117,6 +134,11 @@ class SpecialRowsPartition:
         self.first_row_reader = self.first_column_reader = None
         self.last_row_writer = self.last_column_writer = None
         self._open = {}
+        self._ram = {}                 # id -> cells of the complete rows kept in memory
+        # RAM / disk proportion of the rows written (setRamProportion, :268-271): SpecialRowsArea.create_partition sets
+        # the area's budgets; a partition made on its own keeps its rows on disk
+        self.ram_proportion, self.disk_proportion = 0, 1
+        self.ram_count = self.disk_count = 0
         self.rows = []                 # ids (i - i0) of complete rows, ascending (the first row, id 0, is implicit)
         self.reading = None            # SpecialRowReader handed out last
         self._reading_idx = 0
@@ -144,8 +166,20 @@ class SpecialRowsPartition:
                 rows.append(int(fn, 16))
             elif fn[:1] in ("C", "R") and len(fn) > 10 and fn[9] == ".":
                 self._load_border_reader(fn)
-        self.rows = sorted(rows)
+        self.rows = sorted(set(rows) | set(self._ram))
         self.reload()
+
+    def set_ram_proportion(self, ram, disk):
+        self.ram_proportion, self.disk_proportion = ram, disk
+
+    def _next_row_on_disk(self):
+        """getSpecialRow (:316-333): rows alternate between disk and memory in the proportion of the two budgets"""
+        if (self.disk_proportion != 0 and self.ram_proportion == 0) or \
+                self.ram_count * self.disk_proportion > self.ram_proportion * self.disk_count:
+            self.disk_count += 1
+            return True
+        self.ram_count += 1
+        return False
 
     def _load_border_reader(self, fn):
         """loadBorderReader (:490-515): how a border was made is in the marker's name"""
@@ -226,13 +260,22 @@ class SpecialRowsPartition:
                 if rid + self.i0 < max_i and row.offset < max_j - self.j0 + 1:
                     raise RuntimeError("special row %08X of %s kept by the crosspoint (%d,%d) holds %d of %d cells"
                                        % (rid, self.path, max_i, max_j, row.offset, max_j - self.j0 + 1))
-                row.f.close()
-                os.replace(row.tmp, row.final)      # SpecialRowFile::close renames whatever was written
+                if isinstance(row, _OpenRamRow):
+                    self._ram[rid] = row.cells
+                else:
+                    row.f.close()
+                    os.replace(row.tmp, row.final)      # SpecialRowFile::close renames whatever was written
                 if rid not in self.rows:
                     self.rows.append(rid)
             self._open = {}
             keep, cells = [], max_j - self.j0 + 1
             for rid in sorted(self.rows):
+                if rid in self._ram:                    # SpecialRowRAM::truncateRow does nothing; dropped rows are freed
+                    if rid + self.i0 >= max_i:
+                        del self._ram[rid]
+                    else:
+                        keep.append(rid)
+                    continue
                 fn = os.path.join(self.path, "%08X" % rid)
                 if rid + self.i0 >= max_i:
                     os.remove(fn)
@@ -264,7 +307,14 @@ class SpecialRowsPartition:
         return os.path.join(self.path, "%08X" % (i - self.i0))
 
     def read_row(self, i):
+        if (i - self.i0) in self._ram:
+            return self._ram[i - self.i0]
         return np.fromfile(self.row_filename(i), dtype=np.int32).reshape(-1, 2)
+
+    def last_disk_row_id(self):
+        """absolute DP row of the last complete row ON DISK (what a later process can continue from)"""
+        disk = [r for r in self.rows if r not in self._ram]
+        return self.i0 + (disk[-1] if disk else 0)
 
     # -- border markers (setBorderReader, :125-175) ------------------------------------------------------------
     def set_border_markers(self, first_row_type, first_row_offset, first_col_type, first_col_offset):
@@ -283,10 +333,14 @@ class SpecialRowsPartition:
         rid = i - self.i0
         row = self._open.get(rid)
         if row is None:
-            row = self._open[rid] = _OpenRow(self.path, rid, self.width_cells)
+            row = self._open[rid] = (_OpenRow(self.path, rid, self.width_cells) if self._next_row_on_disk()
+                                     else _OpenRamRow(rid, self.width_cells))
         row.write(cells)
         if row.offset >= self.width_cells:
-            row.close()
+            if isinstance(row, _OpenRamRow):
+                self._ram[rid] = row.cells
+            else:
+                row.close()
             del self._open[rid]
             if rid not in self.rows:
                 self.rows.append(rid)
@@ -296,23 +350,27 @@ class SpecialRowsPartition:
 
     def close(self):
         for row in self._open.values():
-            row.f.close()              # incomplete rows stay .tmp: the next read_directory() removes them
+            if not isinstance(row, _OpenRamRow):
+                row.f.close()          # incomplete rows stay .tmp: the next read_directory() removes them
         self._open = {}
 
     # -- resume (continueFromLastRow, :454-462) ----------------------------------------------------------------
     def continue_from_last_row(self):
         """(row to continue from, its cells): the last complete row becomes the first row of the rest of the
         partition; the caller advances its first-column reader by (row - i0) cells"""
-        i = self.last_row_id()
+        i = self.last_disk_row_id()
         return i, self.read_row(i)
 
 
 class SpecialRowsArea:
     """M/common/sra/SpecialRowsArea.cpp: the partitions of one stage (one directory)"""
 
-    def __init__(self, directory, persistent=True):
+    def __init__(self, directory, persistent=True, ram_limit=0, disk_limit=1):
+        """ram_limit / disk_limit: the two budgets (--ram-size, --disk-size); only their proportion matters here --
+        rows alternate between memory and disk accordingly.  The default keeps every row on disk."""
         self.directory = directory
         self.persistent = persistent
+        self.ram_limit, self.disk_limit = max(int(ram_limit), 0), max(int(disk_limit), 0)
         self.partitions = {}
         self._anonymous = []           # non-persistent partitions have no path to be keyed by
         self.rows = 0
@@ -322,6 +380,7 @@ class SpecialRowsArea:
 
     def create_partition(self, i0, j0, i1, j1):
         p = SpecialRowsPartition(self.directory, i0, j0, i1, j1, persistent=self.persistent)
+        p.set_ram_proportion(self.ram_limit, self.disk_limit)
         if self.persistent:
             self.partitions[p.path] = p
         else:
@@ -335,7 +394,7 @@ class SpecialRowsArea:
         if p is None:
             p = self.partitions[path] = SpecialRowsPartition(self.directory, i0, j0, i1, j1, read_only=True)
         else:
-            p.reload()
+            p.read_directory()         # rows on disk + the rows this object keeps in memory, border readers from the markers
         return p
 
     def open_partition_at(self, i, j):
@@ -368,6 +427,17 @@ class SpecialRowsArea:
 
     def partitions_count(self):
         return len(self.partitions)
+
+
+def get_area(areas, work, stage, ident=0, deep=-1, ram_limit=0, disk_limit=1):
+    """Job::getSpecialRowsArea (M/common/Job.cpp:273-297): one area object per directory for the life of `areas` (a
+    dict the caller keeps across stages) -- rows a stage kept in memory are only there for the stages that share it"""
+    d = special_rows_path(work, stage, ident, deep)
+    if areas is None:
+        return SpecialRowsArea(d, ram_limit=ram_limit, disk_limit=disk_limit)
+    if d not in areas:
+        areas[d] = SpecialRowsArea(d, ram_limit=ram_limit, disk_limit=disk_limit)
+    return areas[d]
 
 
 class Status:

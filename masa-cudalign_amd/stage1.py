@@ -69,7 +69,7 @@ def _crosspoints_on_disk(work):
 
 def stage1(aligner, seq0, seq1, work, alignment_start=AT_ANYWHERE, alignment_end=AT_ANYWHERE, sra_limit=0,
            block_pruning=True, manager_class=Stage1Manager, bounds=None, progress=None, progress_interval=2.0,
-           max_alignments=1):
+           max_alignments=1, ram_limit=0, areas=None):
     """Runs (or resumes) stage 1 of seq0 x seq1 in work directory `work`.  `aligner` is an MI355Aligner; create it
     with a fixed strip height (rows_per_lane) when the area must be resumable or shared with CUDAlign: special rows
     sit on multiples of the strip height (1024 or 2048 rows give CUDAlign's 8192-row spacing).
@@ -79,6 +79,10 @@ def stage1(aligner, seq0, seq1, work, alignment_start=AT_ANYWHERE, alignment_end
     `progress`: a text stream (sys.stderr) that gets MASA-Core's progress line every `progress_interval` seconds while
     the aligner runs -- "(0h00m02s) best:(i,j,score) PROGRESS: d/D strips" (logStatus, sw_stage1.cpp:112-128; the status
     file itself is saved with every completed special row, not by this timer).
+    `sra_limit` is the DISK budget of the special rows (--disk-size), `ram_limit` the part kept in memory instead
+    (--ram-size): rows alternate between the two in proportion, the spacing follows their sum; rows in memory are only
+    there for later stages that get the same `areas` dict (pipeline.py does), and a resumed run continues from the last
+    row on disk.
     `max_alignments` > 1 (--max-alignments): the best-score list keeps that many end points of different alignments
     (BestScoreList), one crosspoint_01.NN each; candidates are what the aligner dispatches (one best cell per strip).
     Returns {"best": (i, j, score) in 1-based DP coordinates, "bests": the whole list, "resumed_from": row or None, "seconds", "gcups", ...}."""
@@ -88,12 +92,14 @@ def stage1(aligner, seq0, seq1, work, alignment_start=AT_ANYWHERE, alignment_end
         raise ValueError("stage1: bounds %r outside the %d x %d matrix" % (bounds, m, n))
     os.makedirs(work, exist_ok=True)
     status = sra_mod.Status(work)
-    interval = sra_mod.flush_interval(m, n, sra_limit) if sra_limit > 0 else 0
+    budget = max(sra_limit, 0) + max(ram_limit, 0)                      # Job::getSRALimit (Job.cpp:354-364)
+    interval = sra_mod.flush_interval(m, n, budget) if budget > 0 else 0
     fr, fc = border_readers(alignment_start)
     i0, resumed_from, part_sra = bi0, None, None
-    if sra_limit > 0:
-        part_sra = sra_mod.SpecialRowsPartition(sra_mod.special_rows_path(work, 1, 0), bi0, bj0, bi1, bj1)
-        last = part_sra.last_row_id()
+    area = sra_mod.get_area(areas, work, 1, 0, ram_limit=ram_limit, disk_limit=sra_limit)
+    if budget > 0:
+        part_sra = area.create_partition(bi0, bj0, bi1, bj1)
+        last = part_sra.last_disk_row_id()
         if last == bi1 and status.loaded:
             # "Stage 1 was already executed" (sw_stage1.cpp:212-214)
             return {"best": status.best, "bests": _crosspoints_on_disk(work), "resumed_from": bi1, "seconds": 0.0, "gcups": 0.0, "already_done": True,
@@ -108,8 +114,7 @@ def stage1(aligner, seq0, seq1, work, alignment_start=AT_ANYWHERE, alignment_end
     else:
         # no budget for special rows: the partition's directory and border markers still exist, as MASA-Core's
         # (SpecialRowsArea::createSplittedPartitions) -- stage 2 then walks back over ONE partition, to its first row
-        sra_mod.SpecialRowsPartition(sra_mod.special_rows_path(work, 1, 0), bi0, bj0, bi1, bj1).set_border_markers(
-            fr.getType(), 0, fc.getType(), 0)
+        area.create_partition(bi0, bj0, bi1, bj1).set_border_markers(fr.getType(), 0, fc.getType(), 0)
     part = Partition(i0, bj0, bi1, bj1)
     sup = Partition(bi0, bj0, bi1, bj1)
     v0, v1 = seq0[bi0:bi1], seq1[bj0:bj1]       # AlignerManager::setSequences (:168-176): the aligner sees the trimmed data

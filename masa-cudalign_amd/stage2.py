@@ -65,7 +65,8 @@ def find_next_crosspoint(mgr, area, c0, c1, alignment_start, must_find=True, goa
     return Crosspoint(i, j, score, typ)
 
 
-def stage2(aligner, seq0, seq1, work, alignment_start=AT_ANYWHERE, sra_limit=0, ident=0, bounds=None):
+def stage2(aligner, seq0, seq1, work, alignment_start=AT_ANYWHERE, sra_limit=0, ident=0, bounds=None, ram_limit=0,
+           areas=None):
     """Runs stage 2 for alignment `ident` of work directory `work` (stage 1 must have left crosspoint_01.NN and,
     with sra_limit > 0, its special rows there).  seq0 / seq1: the whole sequences; `bounds` = (i0, j0, i1, j1) the
     part --trim selected for stage 1 (only its origin matters here: where a global alignment must begin).  Returns {"crosspoints": [(type, i, j, score), ...] as written to
@@ -77,8 +78,9 @@ def stage2(aligner, seq0, seq1, work, alignment_start=AT_ANYWHERE, sra_limit=0, 
     seq_h = np.ascontiguousarray(s0[::-1])
     len_v, len_h = n, m
     bi0, bj0, bi1, bj1 = bounds if bounds is not None else (0, 0, m, n)
-    area1 = sra_mod.SpecialRowsArea(sra_mod.special_rows_path(work, 1, 0))
-    area2 = sra_mod.SpecialRowsArea(sra_mod.special_rows_path(work, 2, ident))
+    budget = max(sra_limit, 0) + max(ram_limit, 0)
+    area1 = sra_mod.get_area(areas, work, 1, 0, ram_limit=ram_limit, disk_limit=sra_limit)
+    area2 = sra_mod.get_area(areas, work, 2, ident, ram_limit=ram_limit, disk_limit=sra_limit)
     cps1 = CrosspointsFile(crosspoint_file(work, 1, ident)).load()
     if not cps1:
         raise RuntimeError("stage 2: no crosspoint_01.%02d in %s" % (ident, work))
@@ -91,8 +93,8 @@ def stage2(aligner, seq0, seq1, work, alignment_start=AT_ANYWHERE, sra_limit=0, 
     mgr = AlignerManager(aligner)
     mgr.setRecurrenceType(NEEDLEMAN_WUNSCH)
     mgr.setBlockPruning(False)
-    if part1 is not None and sra_limit > 0:
-        mgr.setSpecialRowInterval(sra_mod.flush_intervals(m, n, sra_limit)[1])
+    if part1 is not None and budget > 0:
+        mgr.setSpecialRowInterval(sra_mod.flush_intervals(m, n, budget)[1])
     else:
         mgr.setSpecialRowInterval(0)
     out = CrosspointsFile(crosspoint_file(work, 2, ident)).open()

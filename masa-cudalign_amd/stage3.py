@@ -94,17 +94,17 @@ def _reduce_partitions(mgr, prev, out, seq_v, seq_h, area_prev, area, reverse):
     return sweeps
 
 
-def stage3(aligner, seq0, seq1, work, sra_limit=0, ident=0):
+def stage3(aligner, seq0, seq1, work, sra_limit=0, ident=0, ram_limit=0, areas=None):
     """Runs stage 3 for alignment `ident`.  Returns {"crosspoints": the final list [(type, i, j, score)] in original
     coordinates (also written to crosspoint_03.NN), "rounds": [(crosspoints in, crosspoints out, sweeps)], "seconds"}."""
     t_start = time.time()
     seq_v, seq_h = np.ascontiguousarray(_as_u8(seq0)), np.ascontiguousarray(_as_u8(seq1))
     m, n = len(seq_v), len(seq_h)
-    intervals = sra_mod.flush_intervals(m, n, sra_limit)
+    intervals = sra_mod.flush_intervals(m, n, max(sra_limit, 0) + max(ram_limit, 0))
     mgr = AlignerManager(aligner)
     mgr.setRecurrenceType(NEEDLEMAN_WUNSCH)
     mgr.setBlockPruning(False)
-    area_prev = sra_mod.SpecialRowsArea(sra_mod.special_rows_path(work, 2, ident))
+    area_prev = sra_mod.get_area(areas, work, 2, ident, ram_limit=ram_limit, disk_limit=sra_limit)
     prev = CrosspointsFile(crosspoint_file(work, 2, ident)).load()
     if not prev:
         raise RuntimeError("stage 3: no crosspoint_02.%02d in %s" % (ident, work))
@@ -118,7 +118,7 @@ def stage3(aligner, seq0, seq1, work, sra_limit=0, ident=0):
         deep += 1
         prev.reverse_all(len(seq_h), len(seq_v))          # :352: into this round's orientation, start -> end
         cur = CrosspointsFile(crosspoint_file(work, 3, ident, deep)).open()
-        area = sra_mod.SpecialRowsArea(sra_mod.special_rows_path(work, 3, ident, deep))
+        area = sra_mod.get_area(areas, work, 3, ident, deep, ram_limit=ram_limit, disk_limit=sra_limit)
         if interval < MIN_INTERVAL:
             mgr.setSpecialRowInterval(MIN_INTERVAL)
             save = False
@@ -132,7 +132,7 @@ def stage3(aligner, seq0, seq1, work, sra_limit=0, ident=0):
             break
         if area.rows_count() <= area.partitions_count():  # nothing but first rows saved: nothing left to split at
             break
-        prev, area_prev = cur, sra_mod.SpecialRowsArea(sra_mod.special_rows_path(work, 3, ident, deep))
+        prev, area_prev = cur, area                      # Job::getSpecialRowsArea hands the same object back (:352-353)
         seq_v, seq_h = np.ascontiguousarray(seq_h[::-1]), np.ascontiguousarray(seq_v[::-1])
     if deep % 2 == 0:
         cur.reverse_all(len(seq_v), len(seq_h))

@@ -323,6 +323,40 @@ def test_random_configurations_against_the_live_reference(seed, pkg, oracle, tmp
         assert filecmp.cmp(os.path.join(rwork, f), os.path.join(work, f), shallow=False), (args, f)
 
 
+@pytest.mark.parametrize("name,ram,disk", [("half_and_half", 150 * 1024, 150 * 1024), ("memory_only", 300 * 1024, 0),
+                                           ("one_third_memory", 100 * 1024, 200 * 1024), ("mostly_memory", 250 * 1024, 50 * 1024)])
+def test_special_rows_in_memory_and_on_disk(name, ram, disk, pkg, oracle, tmp_path):
+    """--ram-size / --disk-size: rows alternate between memory and disk in the proportion of the two budgets
+    (SpecialRowsPartition::getSpecialRow), the spacing follows their sum, and the later stages find the rows kept in
+    memory through the shared area objects (Job::getSpecialRowsArea).  Same rows on disk as MASA-Core -- names and
+    bytes, in every stage's directory --, same crosspoint files, same text"""
+    if not oracle.have_ref():
+        pytest.skip("oracle/_ref not built (needs /root/reference)")
+    from oracle.aligner_double import SerialBlockAligner
+    from masa_cudalign_amd import pipeline
+    s0, s1 = pkg.seqgen.related_pair(12000, 12000, cfg=21, p_indel=0.02, indel_mean=6.0)
+    refdir = tmp_path / "ref"
+    refdir.mkdir()
+    ref = oracle.run_ref(s0, s1, ["--block=128,128", "--no-block-pruning", "--ram-size=%d" % ram, "--disk-size=%d" % disk],
+                         workdir=str(refdir), timeout=600)
+    rwork = str(refdir / "work")
+    q0, q1 = _fasta(pkg, s0, s1)
+    work = str(tmp_path / "native")
+    out = pipeline.align(SerialBlockAligner(128, 128), q0, q1, work, sra_limit=disk, ram_limit=ram, block_pruning=False)
+    for f in sorted(os.listdir(os.path.join(rwork, "crosspoints"))):
+        assert filecmp.cmp(os.path.join(rwork, "crosspoints", f), os.path.join(work, "crosspoints", f), shallow=False), f
+    assert out["text"] == ref["alignment_txt"]
+    on_disk = 0
+    for d in sorted(os.listdir(os.path.join(rwork, "special_rows"))):
+        p = subprocess.run(["diff", "-rq", "-x", "%08X" % len(s0), os.path.join(rwork, "special_rows", d),
+                            os.path.join(work, "special_rows", d)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+        assert p.returncode == 0, p.stdout.decode()[:2000]
+        for _root, _dirs, files in os.walk(os.path.join(rwork, "special_rows", d)):
+            on_disk += sum(1 for f in files if len(f) == 8)
+    assert (on_disk == 0) == (disk == 0)
+    assert len(out["stage2"]["crosspoints"]) > 3              # the rows in memory were found: the traceback used them
+
+
 def _three_segments(pkg, seed=5):
     g = pkg.seqgen
     a, b, c = g.random_dna(100 + seed, 2000), g.random_dna(200 + seed, 1500), g.random_dna(300 + seed, 900)

@@ -186,3 +186,30 @@ def test_progress_line_of_stage1(pkg, oracle, tmp_path):
     lines = buf.getvalue().splitlines()
     assert lines and all(ln.startswith("(0h00m0") and " best:(" in ln and "PROGRESS: " in ln for ln in lines)
     assert r["best"][2] == oracle.stage1(s0, s1)["best"][2]
+
+
+def test_resume_continues_from_the_last_row_on_disk(pkg, oracle, tmp_path):
+    """rows kept in memory (--ram-size) die with the process: a resumed stage 1 continues from the last row that reached
+    the disk and still ends with the uninterrupted run's best score"""
+    s0, s1 = make_pair(pkg, CASE["seq"])
+    work = str(tmp_path / "w")
+
+    class Killed(Exception):
+        pass
+
+    class DyingManager(pkg.Stage1Manager):
+        def dispatchRow(self, i, buf, length):
+            pkg.Stage1Manager.dispatchRow(self, i, buf, length)
+            if 16384 in self.sra.rows:                   # rows 8192 (memory) and 16384 (disk) are complete
+                self.active = False
+                raise Killed()
+    with pytest.raises(Killed):
+        pkg.stage1(OracleAligner(oracle, strip_rows=1024), s0, s1, work, sra_limit=100 * 1024, ram_limit=100 * 1024,
+                   block_pruning=False, manager_class=DyingManager)
+    d = os.path.join(work, "special_rows", "stage.01.00", list(CASE["sra_listing"])[0])
+    on_disk = sorted(int(fn, 16) for fn in os.listdir(d) if len(fn) == 8)
+    assert on_disk == [16384]                                 # row 8192 was only in memory
+    res = pkg.stage1(OracleAligner(oracle, strip_rows=1024), s0, s1, work, sra_limit=100 * 1024, ram_limit=100 * 1024,
+                     block_pruning=False)
+    assert res["resumed_from"] == on_disk[-1]
+    assert tuple(res["best"]) == tuple(CASE["best"])

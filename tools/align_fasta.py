@@ -3,7 +3,8 @@ MI355X) behind the handful of MASA-CUDAlign options that concern the path -- not
 
     python tools/align_fasta.py [options] seq0.fasta seq1.fasta
       --work-dir=DIR            work directory in MASA-Core's layout (default ./work.tmp); a killed stage 1 resumes from it
-      --disk-size=N[KMG]        Special Rows Area budget (default: 8192-row spacing, at most 4 GiB; the traceback needs special rows)
+      --disk-size=N[KMG]        Special Rows Area budget on disk (default: 8192-row spacing, at most 4 GiB; the traceback needs special rows)
+      --ram-size=N[KMG]         part of the special rows kept in memory instead (they alternate with the rows on disk)
       --trim=I0,I1,J0,J1  --reverse=1|2|both  --complement=1|2|both  --reverse-complement=1|2|both  --clear-n
       --alignment-edges=XY      X start, Y end: * anywhere (local), 1 / 2 on that sequence's edge, 3 on either, + on both (global)
       --max-alignments=N        trace back up to N different alignments (alignment.00.txt .. alignment.NN.txt)
@@ -33,7 +34,7 @@ def main(argv):
     from masa_cudalign_amd import fasta, pipeline, stage1
     edge = {"*": pkg.AT_ANYWHERE, "1": pkg.AT_SEQUENCE_1, "2": pkg.AT_SEQUENCE_2, "3": pkg.AT_SEQUENCE_1_OR_2,
             "+": pkg.AT_SEQUENCE_1_AND_2}
-    work, limit, device, prune, only1, edges, count = "./work.tmp", None, 0, True, False, "**", 1
+    work, limit, device, prune, only1, edges, count, ram = "./work.tmp", None, 0, True, False, "**", 1, 0
     trim, rev, comp, clear_n = [0, 0, 0, 0], [False, False], [False, False], False
     files = []
     for a in argv:
@@ -41,6 +42,8 @@ def main(argv):
             work = a[11:]
         elif a.startswith("--disk-size="):
             limit = _size(a[12:])
+        elif a.startswith("--ram-size="):
+            ram = _size(a[11:])
         elif a.startswith("--trim="):
             trim = [int(x) for x in a[7:].split(",")]
         elif a.startswith("--reverse="):
@@ -77,11 +80,11 @@ def main(argv):
             bounds = (seqs[0].offset0 - 1, seqs[1].offset0 - 1, seqs[0].offset1, seqs[1].offset1)
             r = stage1.stage1(al, seqs[0].data(), seqs[1].data(), work, alignment_start=edge[edges[0]],
                               alignment_end=edge[edges[1]], sra_limit=limit, block_pruning=prune, bounds=bounds,
-                              progress=sys.stderr, max_alignments=count)
+                              progress=sys.stderr, max_alignments=count, ram_limit=ram)
             res = {"best": list(r["best"]), "seconds": {"1": r["seconds"]}, "gcups": r["gcups"]}
         else:
             out = pipeline.align(al, seqs[0], seqs[1], work, alignment_start=edge[edges[0]], alignment_end=edge[edges[1]],
-                                 sra_limit=limit, block_pruning=prune, progress=sys.stderr, max_alignments=count)
+                                 sra_limit=limit, block_pruning=prune, progress=sys.stderr, max_alignments=count, ram_limit=ram)
             res = {"best": list(out["best"]), "seconds": {str(k): v for k, v in out["seconds"].items()},
                    "crosspoints": {str(k): v for k, v in out["crosspoints"].items()},
                    "alignments": [os.path.join(work, "alignment.%02d.txt" % k) for k in range(len(out["alignments"]))]}
