@@ -262,7 +262,7 @@ def test_native_stages_continue_a_work_directory_of_masa_core(pkg, oracle, tmp_p
 
 def _random_case(pkg, rng):
     """one random configuration of everything the native drivers take: pair kind and divergence, sizes, block geometry,
-    special-rows budget, alignment edges, --max-alignments, --trim"""
+    special-rows budgets on disk and in memory, alignment edges, --max-alignments, --trim"""
     g = pkg.seqgen
     m, n, cfg = rng.randint(600, 6000), rng.randint(600, 6000), rng.randint(1, 10000)
     kind = rng.choice(["related", "related", "related", "unrelated", "contained"])
@@ -279,7 +279,7 @@ def _random_case(pkg, rng):
     case = dict(s0=s0, s1=s1, bh=rng.choice([64, 100, 128, 256, 300, 1024]), bw=rng.choice([64, 128, 200, 512, 2048]),
                 limit=rng.choice([0, 20 * 1024, 60 * 1024, 150 * 1024, 400 * 1024, 2 * 1024 * 1024]),
                 edges=rng.choice(["**", "**", "**", "++", "13", "31", "21", "12", "22", "11", "33", "2*", "3*"]),
-                count=rng.choice([1, 1, 1, 2, 3]), mod0={}, mod1={}, flags=[])
+                count=rng.choice([1, 1, 1, 2, 3]), mod0={}, mod1={}, flags=[], ram=rng.choice([0, 0, 50 * 1024, 200 * 1024]))
     if rng.random() < 0.3:
         a0, b0 = rng.randint(1, len(s0) // 3), rng.randint(2 * len(s0) // 3, len(s0))
         a1, b1 = rng.randint(1, len(s1) // 3), rng.randint(2 * len(s1) // 3, len(s1))
@@ -300,8 +300,8 @@ def test_random_configurations_against_the_live_reference(seed, pkg, oracle, tmp
     c = _random_case(pkg, random.Random(1000 + seed))
     edge = {"*": pkg.AT_ANYWHERE, "1": pkg.AT_SEQUENCE_1, "2": pkg.AT_SEQUENCE_2, "3": pkg.AT_SEQUENCE_1_OR_2,
             "+": pkg.AT_SEQUENCE_1_AND_2}
-    args = ["--disk-size=%d" % c["limit"], "--block=%d,%d" % (c["bh"], c["bw"]), "--no-block-pruning",
-            "--max-alignments=%d" % c["count"]] + c["flags"]
+    args = ["--disk-size=%d" % c["limit"], "--ram-size=%d" % c["ram"], "--block=%d,%d" % (c["bh"], c["bw"]),
+            "--no-block-pruning", "--max-alignments=%d" % c["count"]] + c["flags"]
     if c["edges"] != "**":
         args.append("--edges=" + c["edges"])
     refdir = tmp_path / "ref"
@@ -312,7 +312,8 @@ def test_random_configurations_against_the_live_reference(seed, pkg, oracle, tmp
     q1 = fasta.parse(b">s1\n" + c["s1"].tobytes() + b"\n", fasta.SequenceModifiers(**c["mod1"]))
     work = str(tmp_path / "native")
     pipeline.align(SerialBlockAligner(c["bh"], c["bw"]), q0, q1, work, alignment_start=edge[c["edges"][0]],
-                   alignment_end=edge[c["edges"][1]], sra_limit=c["limit"], block_pruning=False, max_alignments=c["count"])
+                   alignment_end=edge[c["edges"][1]], sra_limit=c["limit"], ram_limit=c["ram"], block_pruning=False,
+                   max_alignments=c["count"])
     rc = os.path.join(rwork, "crosspoints")
     want = sorted(os.listdir(rc)) if os.path.isdir(rc) else []
     got = sorted(os.listdir(os.path.join(work, "crosspoints"))) if os.path.isdir(os.path.join(work, "crosspoints")) else []
