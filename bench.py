@@ -129,6 +129,10 @@ def main():
     import torch
     import torch.distributed as dist
 
+    if os.environ.get("MI355SW_BENCH_STACKS"):      # debugging aid: every rank dumps its Python stacks every N seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["MI355SW_BENCH_STACKS"]), repeat=True, file=sys.stderr)
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

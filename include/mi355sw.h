@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define MI355SW_ABI_VERSION 3
+#define MI355SW_ABI_VERSION 4
 
 /* M/libmasa/libmasaTypes.hpp:35-41  cell_t {int h; union{int f; int e;};} 8-byte aligned */
 typedef struct { int32_t h; int32_t f; } mi355sw_cell;
@@ -197,6 +197,13 @@ typedef struct {
     int32_t first_column_resume_rows;   /* restart of the SAME partition on this handle (int32 rerun after
                                            MI355SW_EOVERFLOW16): rows of the streamed first column that were fed
                                            before the restart are still in place and count as fed again */
+    int32_t share_best;                 /* 1: the running best score of this stream is shared while the kernel runs --
+                                           along a chain of column bands through the column ports (each band's kernel
+                                           pushes its best to the next band's port and reads what the next band
+                                           publishes, so a score found anywhere reaches every band in both directions),
+                                           and with the host through mi355sw_stream_best_hint / _running_best.  Block
+                                           pruning then works against the best of the WHOLE matrix, which the
+                                           reference gives up when it forks (M/libmasa/libmasa.cpp:1318-1321). */
 } mi355sw_stream_params;
 
 int mi355sw_stream_begin(mi355sw_handle* h, const mi355sw_partition* partition, const mi355sw_stream_params* p);
@@ -210,11 +217,20 @@ int mi355sw_stream_read_column(mi355sw_handle* h, int32_t row, mi355sw_cell* cel
 int mi355sw_stream_read_special_row(mi355sw_handle* h, int32_t k, int32_t* dp_row, mi355sw_cell* cells, int32_t col, int32_t len);
 int mi355sw_stream_read_last_row(mi355sw_handle* h, mi355sw_cell* cells, int32_t col, int32_t len);
 int mi355sw_stream_abort(mi355sw_handle* h);
+/* share_best streams: `score` is the score of an alignment that exists somewhere in the super-partition (found by
+ * another band, another node, a previous run): the running kernel folds it into its pruning bound at its next strip
+ * hand-over.  Lower bounds only -- a value no alignment reaches would prune the optimum away. */
+int mi355sw_stream_best_hint(mi355sw_handle* h, int32_t score);
+/* share_best streams: the best score the kernel knew at its last strip hand-over (its own cells and every hint it
+ * received; -MI355SW_INF before the first).  May be called from any thread while the stream runs. */
+int mi355sw_stream_running_best(mi355sw_handle* h, int32_t* score);
 /* waits for the kernel; best = canonical (max score, min i, min j), sequence-relative 0-based cell */
 int mi355sw_stream_end(mi355sw_handle* h, mi355sw_score* best, int32_t* n_special_rows);
 /* per-strip best scores of the finished stream (for dispatch_score); returns count written */
 int mi355sw_stream_strip_scores(mi355sw_handle* h, mi355sw_score* out, int32_t max_count);
 /* ---- column ports: the boundary column of a band chain, GPU to GPU over xGMI -------------------------------
+ * (and, for share_best streams, the running best score: two more words in the port's control block, one written by
+ *  each side, next to the row counter)
  * Replaces the reference's socket chain between forked processes (M/libmasa/libmasa.cpp:540-642,
  * M/common/io/SocketCellsWriter.cpp, BufferedCellsWriter.cpp:57-66).  Band g+1 owns an inbound PORT in the HBM
  * of its own GPU: (H,E) cells of its first column plus a row counter (fine-grained memory).  Band g maps that

@@ -90,6 +90,14 @@ class BandRunner:
         self.restarts = 0            # packed-kernel overflow restarts (int32 rerun) of the last run
         self.p2p_error = None        # why probe_p2p() / verify_p2p() failed on this rank
         self.inbound_crc = None      # crc32 of the inbound boundary column of the last run(digest_inbound=True)
+        self.special_rows = []       # DP rows of the special rows the last run handed to its sink
+        self.hints = 0               # best-score hints this band took from the others in the last run (host transport)
+        # Block pruning over a chain of bands needs the best of the WHOLE matrix (the reference switches pruning off
+        # when it forks, libmasa.cpp:1318-1321).  Between GPUs the kernels share it through the column ports; on the
+        # host transport a side thread does, with one small all_reduce(MAX) every few milliseconds on its own group.
+        self._best_group = None
+        if prune_blocks and world > 1 and dist is not None and hasattr(dist, "new_group"):
+            self._best_group = dist.new_group(list(range(world)), backend="gloo")
 
     def _tensor(self, rows):
         import torch
@@ -203,10 +211,16 @@ class BandRunner:
 
     def run(self, m, j0, j1, recurrence=SMITH_WATERMAN, track_best=True, first_row_init_type=INIT_WITH_ZEROES,
             first_col_init_type=INIT_WITH_ZEROES, poll_sleep=0.0005, want_last_row=False, before_end=None,
-            force_int32=False, digest_inbound=False):
+            force_int32=False, digest_inbound=False, special_row_interval=0, special_row_sink=None, n_total=None):
         """seq1 of the engine must already hold the whole horizontal sequence (or at least [j0,j1)).
         digest_inbound: leave the crc32 of the boundary column this band received in self.inbound_crc (host transport:
-        the segments as they arrive; p2p: the port's memory, read back once the band is through)."""
+        the segments as they arrive; p2p: the port's memory, read back once the band is through).
+        special_row_interval > 0: the band keeps its [j0, j1) slice of every special row (the reference: one Special
+        Rows Area per forked node, work.tmp/FORK.NN, Job.cpp:123-128); `special_row_sink(dp_row, first_cell, cells)`
+        gets each row as soon as its strip is complete -- cells = (H,F) of columns j0..j1-1, first_cell = the boundary
+        column's cell of that row with f = -INF (AbstractDiagonalAligner.cpp:290-298).
+        n_total: width of the whole matrix (default j1 of the last band = this band's j1): block pruning bounds what an
+        alignment can still gain by the rows and columns left in the SUPER-partition (M3)."""
         import zlib
         from .engine import AlignerError
         self.inbound_crc = 0 if digest_inbound else None
@@ -216,13 +230,18 @@ class BandRunner:
         part = Partition(0, j0, m, j1)
         seg = self.segment_rows
         nseg = (m + seg - 1) // seg
+        prune = bool(self.prune_blocks and recurrence == SMITH_WATERMAN and track_best)
         kw = dict(recurrence_type=recurrence, track_best=track_best,
                   first_row_init_type=first_row_init_type, first_row_start_offset=j0,
                   want_last_column=(not last) and not p2p, last_column_port=(not last) and p2p,
-                  want_last_row=want_last_row, force_int32=force_int32,
-                  # block pruning: never when the matrix is split over processes (as the reference,
-                  # libmasa.cpp:1318-1321); for a single band it is the caller's choice (self.prune_blocks)
-                  prune_blocks=(self.prune_blocks and self.world == 1 and recurrence == SMITH_WATERMAN and track_best))
+                  want_last_row=want_last_row, force_int32=force_int32)
+        if special_row_interval > 0:
+            kw.update(special_row_interval=int(special_row_interval))
+        if prune:
+            # every band prunes against the best of the whole chain (share_best) and bounds the gain still possible
+            # by the extents of the whole matrix, not of its own band
+            kw.update(prune_blocks=True, prune_rows=m, prune_cols=(n_total if n_total is not None else j1) - j0,
+                      share_best=self.world > 1)
         if first:
             kw.update(first_column_init_type=first_col_init_type)
         else:
@@ -253,6 +272,11 @@ class BandRunner:
                     dist.recv(buf, src=self.rank - 1)
                     if digest_inbound:
                         self.inbound_crc = zlib.crc32(buf.numpy().tobytes(), self.inbound_crc)
+                    if inbound_h is not None:          # H of the boundary column at every possible special row
+                        q0 = r0 // 256 + 1
+                        q1 = (r0 + ln) // 256
+                        if q1 >= q0:
+                            inbound_h[q0:q1 + 1] = buf.numpy()[q0 * 256 - 1 - r0:q1 * 256 - r0:256, 0]
                     with lock:
                         eng.streamFeedColumn(r0, buf.numpy())
                         fed[0] = r0 + ln
@@ -277,6 +301,83 @@ class BandRunner:
                 kw2["first_column_resume_rows"] = fed[0]
             eng.streamBegin(part, **kw2)
             self.restarts += 1
+            reprobe_special()
+
+        # special rows of this band: DP rows (multiples of the strip height, AbstractDiagonalAligner::isSpecialRow)
+        # (special rows sit on multiples of the strip height, every strip height is a multiple of 256: the boundary
+        #  column's H at every 256th row covers whatever geometry a restart on the int32 kernels picks)
+        special_dp, special_next = [], [0]
+        inbound_h = np.zeros(m // 256 + 2, dtype=np.int32) if (special_row_interval > 0 and not first and not p2p) else None
+        if special_row_interval > 0:
+            while True:
+                try:
+                    dp, _ = eng.streamReadSpecialRow(len(special_dp), 0, 0)
+                except (AlignerError, IndexError):
+                    break
+                special_dp.append(int(dp))
+        self.special_rows = []
+
+        def reprobe_special():
+            """after a restart on the int32 kernels (other strip heights): the rows already handed over stay, the rest
+            are where the new geometry puts them"""
+            if special_row_interval <= 0:
+                return
+            done_to = self.special_rows[-1] if self.special_rows else 0
+            del special_dp[:]
+            while True:
+                try:
+                    dp, _ = eng.streamReadSpecialRow(len(special_dp), 0, 0)
+                except (AlignerError, IndexError):
+                    break
+                special_dp.append(int(dp))
+            special_next[0] = sum(1 for dp in special_dp if dp <= done_to)
+
+        def flush_special(rows_ok):
+            """hands over every special row whose strip is complete; called with the lock held"""
+            while special_next[0] < len(special_dp) and special_dp[special_next[0]] <= rows_ok:
+                k, dp = special_next[0], special_dp[special_next[0]]
+                if not first and not p2p and fed[0] < dp:
+                    return                                  # its boundary cell is still on the way
+                _, cells = eng.streamReadSpecialRow(k)
+                if first:
+                    c0 = np.array([0 if first_col_init_type == INIT_WITH_ZEROES
+                                   else -2 * dp - (3 if first_col_init_type == 1 else 0), -INF], dtype=np.int32)
+                elif p2p:
+                    c0 = np.array([int(eng.portRead(dp - 1, 1)[0, 0]), -INF], dtype=np.int32)
+                else:
+                    c0 = np.array([int(inbound_h[dp // 256]), -INF], dtype=np.int32)
+                if special_row_sink is not None:
+                    special_row_sink(dp, c0, cells)
+                self.special_rows.append(dp)
+                special_next[0] += 1
+
+        # host transport: the chain's running best travels between the rank processes (p2p: between the kernels)
+        self.hints = 0
+        bx_stop, bx = threading.Event(), None
+        if prune and self.world > 1 and not p2p and self._best_group is not None:
+            def best_exchange():
+                import torch
+                known = -INF
+                try:
+                    while True:
+                        mine = eng.streamRunningBest() if not bx_stop.is_set() else -INF
+                        t = torch.tensor([max(mine, known), -1 if bx_stop.is_set() else 0], dtype=torch.int64)
+                        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self._best_group)
+                        if int(t[0]) > known:
+                            known = int(t[0])
+                            if known > mine and not bx_stop.is_set():
+                                try:
+                                    eng.streamBestHint(known)
+                                    self.hints += 1
+                                except AlignerError:
+                                    pass
+                        if int(t[1]) == -1:                  # every band is through
+                            return
+                        time.sleep(0.002)
+                except BaseException as e:
+                    errors.append(e)
+            bx = threading.Thread(target=best_exchange, daemon=True)
+            bx.start()
 
         rx = None
         if not first and not p2p:
@@ -305,6 +406,7 @@ class BandRunner:
                     errors.append(RuntimeError("band %d/%d: no progress for %.0f s (rows_done=%d/%d, segments_sent=%d/%d)"
                                                % (self.rank, self.world, now - t_prog, rows_done, m, send_q, nseg)))
             if errors:
+                bx_stop.set()
                 with lock:
                     eng.streamAbort()
                     try:
@@ -320,6 +422,10 @@ class BandRunner:
                         raise
                     restart_int32()
                     continue
+                # (device-resident rows are read through the copy stream: only once nothing more has to be fed, so that
+                #  a copy held up behind the running kernel cannot starve that kernel of its first column)
+                if special_dp and (first or p2p or fed[0] >= m or fin):
+                    flush_special(rows_done)
             progressed = False
             # outbound boundary column (host transport): every complete segment goes to the right neighbour
             while not last and not p2p and send_q < nseg:
@@ -340,10 +446,14 @@ class BandRunner:
                 time.sleep(poll_sleep)
         if rx is not None:
             rx.join()
+        if special_dp:
+            with lock:
+                flush_special(m)
         if digest_inbound and p2p and not first:
             self.inbound_crc = zlib.crc32(np.ascontiguousarray(eng.portRead(0, m), dtype=np.int32).tobytes())
         if before_end is not None:       # e.g. read this band's slice of the last row while the stream is open
             before_end(eng)
+        bx_stop.set()                   # the exchange thread keeps answering the other bands until every band is through
         try:
             best, _ = eng.streamEnd()
         except AlignerError as e:        # e.g. reported by the exact-position pass of a very tall band
@@ -363,6 +473,10 @@ class BandRunner:
             if before_end is not None:
                 before_end(eng)
             best, _ = eng.streamEnd()
+        if bx is not None:
+            bx.join()
+        if errors:
+            raise errors[0]
         return best
 
     def reduce_best(self, best):

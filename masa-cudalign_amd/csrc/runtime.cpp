@@ -71,6 +71,7 @@ struct mi355sw_handle {
     bool first_col_pinned = false;
     int* h_pinned = nullptr;        // [0] strips_done (kernel->host) [16] first_col_ready (host->kernel) [32] abort (host->kernel)
                                     // [48] error mirror (kernel->host, written before [0] moves past the failing strip)
+                                    // [64] best-score hint (host->kernel, T domain) [80] running best (kernel->host, T domain)
     // column ports (xGMI boundary column): inbound = fine-grained HBM of this GPU, outbound = the next band's inbound
     // port mapped here (hipIpc / peer access).  Layout: 256 control bytes (int32 row counter at +0), then m+1 cells.
     void* in_port = nullptr; size_t in_port_bytes = 0; int in_port_rows = 0;
@@ -197,11 +198,12 @@ int mi355sw_create(const mi355sw_config* config, mi355sw_handle** out) {
     if (hipStreamCreateWithPriority(&h->stream, hipStreamNonBlocking, prio_hi) != hipSuccess ||
         hipStreamCreateWithFlags(&h->copy, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess ||
-        hipHostMalloc((void**) &h->h_pinned, 256, hipHostMallocMapped) != hipSuccess) {
+        hipHostMalloc((void**) &h->h_pinned, 512, hipHostMallocMapped) != hipSuccess) {
         mi355sw_destroy(h);
         return MI355SW_EHIP;
     }
-    memset(h->h_pinned, 0, 256);
+    memset(h->h_pinned, 0, 512);
+    h->h_pinned[64] = h->h_pinned[80] = -MI355SW_INF;
     *out = h;
     return MI355SW_OK;
 }
@@ -576,6 +578,15 @@ int mi355sw_stream_begin(mi355sw_handle* h, const mi355sw_partition* part, const
     a.pruned_slabs = (unsigned long long*) (ctrl + 40);
     a.strip_best = (int4*) h->d_strip_best.p;
     a.dbg = getenv("MI355SW_DEBUG") ? ctrl + 56 : nullptr;
+    // running best shared along the band chain / with the host (packed kernels only: the int32 family keeps no gbest)
+    __atomic_store_n(&h->h_pinned[64], -MI355SW_INF, __ATOMIC_RELEASE);
+    __atomic_store_n(&h->h_pinned[80], -MI355SW_INF, __ATOMIC_RELEASE);
+    if (p->share_best && h->use16 && !getenv("MI355SW_NO_SHARED_BEST")) {
+        if (h->first_col_port) { a.chain_down_in = (const int*) ((char*) h->in_port + 64); a.chain_up_pub = (int*) ((char*) h->in_port + 128); }
+        if (p->last_column_port) { a.chain_down_pub = (int*) ((char*) h->out_port + 64); a.chain_up_in = (const int*) ((char*) h->out_port + 128); }
+        a.host_best_hint = h->h_pinned + 64;
+        a.host_best_report = h->h_pinned + 80;
+    }
     a.trace = nullptr;
     if (getenv("MI355SW_TRACE")) {
         if ((rc = ensure(h, h->d_trace, sizeof(long long) * 4 * (size_t) h->strips))) return rc;
@@ -626,6 +637,8 @@ int mi355sw_stream_begin(mi355sw_handle* h, const mi355sw_partition* part, const
         b.ticket = ctrl2 + 0; b.abort_flag = ctrl2 + 16; b.error_flag = ctrl2 + 32; b.strips_done_dev = ctrl2 + 48;
         b.strips_done_host = nullptr; b.first_col_ready = nullptr; b.host_abort = nullptr;
         b.peer_ready = nullptr; b.host_error = nullptr; b.fault_strip = -1;
+        b.chain_down_in = nullptr; b.chain_up_pub = nullptr; b.chain_down_pub = nullptr; b.chain_up_in = nullptr;
+        b.host_best_hint = nullptr; b.host_best_report = nullptr;
         b.strip_best = (int4*) (base + o_sb);
         b.dbg = nullptr; b.trace = nullptr;
         b.independent = 1;                             // nobody waits for anybody: progress[0..ws] stays "all columns ready"
@@ -672,6 +685,14 @@ static void republish_first_column(mi355sw_handle* h, int rows) {
 // ------------------------------------------------------------------------------------------------
 // column ports
 // ------------------------------------------------------------------------------------------------
+// control block of a fresh port: row counter 0 at +0, the two running-best words (+64 pushed by the previous band,
+// +128 published by the owner) at "nothing known yet"
+static const int* port_control_block() {
+    static int block[64];
+    block[0] = 0; block[16] = -MI355SW_INF; block[32] = -MI355SW_INF;
+    return block;
+}
+
 int mi355sw_port_create(mi355sw_handle* h, int32_t rows, mi355sw_port_handle* out) {
     if (!h || rows <= 0) return MI355SW_EINVAL;
     if (h->active) FAIL(h, MI355SW_ESTATE, "port_create while a stream is active");
@@ -684,7 +705,7 @@ int mi355sw_port_create(mi355sw_handle* h, int32_t rows, mi355sw_port_handle* ou
     if (e != hipSuccess) { h->in_port = nullptr; FAIL(h, MI355SW_ENOMEM, "hipExtMallocWithFlags(%zu, finegrained) failed: %s", bytes, hipGetErrorString(e)); }
     h->in_port_bytes = bytes;
     h->in_port_rows = rows;
-    HIPCHK(h, hipMemset(h->in_port, 0, 256));
+    HIPCHK(h, hipMemcpy(h->in_port, port_control_block(), 256, hipMemcpyHostToDevice));
     HIPCHK(h, hipDeviceSynchronize());
     if (out) {
         memset(out, 0, sizeof(*out));
@@ -740,7 +761,7 @@ int mi355sw_port_reset(mi355sw_handle* h) {
     if (h->active) FAIL(h, MI355SW_ESTATE, "port_reset while a stream is active");
     if (!h->in_port) FAIL(h, MI355SW_ESTATE, "no inbound port");
     HIPCHK(h, hipSetDevice(h->device));
-    HIPCHK(h, hipMemsetAsync(h->in_port, 0, 256, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->in_port, port_control_block(), 256, hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return MI355SW_OK;
 }
@@ -847,6 +868,21 @@ int mi355sw_stream_read_last_row(mi355sw_handle* h, mi355sw_cell* cells, int32_t
     return MI355SW_OK;
 }
 
+int mi355sw_stream_best_hint(mi355sw_handle* h, int32_t score) {
+    if (!h || !h->active) return MI355SW_ESTATE;
+    // the kernel keeps T = H - 3; the word only ever grows (one writer: this thread)
+    const int t = score - 3;
+    if (t > __atomic_load_n(&h->h_pinned[64], __ATOMIC_RELAXED)) __atomic_store_n(&h->h_pinned[64], t, __ATOMIC_RELEASE);
+    return MI355SW_OK;
+}
+
+int mi355sw_stream_running_best(mi355sw_handle* h, int32_t* score) {
+    if (!h || !score) return MI355SW_EINVAL;
+    const int t = __atomic_load_n(&h->h_pinned[80], __ATOMIC_ACQUIRE);
+    *score = (t <= -MI355SW_INF + 3) ? -MI355SW_INF : t + 3;
+    return MI355SW_OK;
+}
+
 int mi355sw_stream_abort(mi355sw_handle* h) {
     if (!h || !h->active) return MI355SW_ESTATE;
     // a store into pinned memory the kernel polls with system scope: a copy, whatever its stream, may be held
@@ -884,6 +920,8 @@ static int run_exact_pass(mi355sw_handle* h, int s_star, int want_score, mi355sw
     b.last_col = nullptr; b.last_row = nullptr; b.ckpt_rows = nullptr; b.ckpt_interval_strips = 0;
     b.first_col_ready = nullptr;        // every row of a streamed first column has arrived by now
     b.peer_ready = nullptr;             // the boundary column was published by the main pass
+    b.chain_down_in = nullptr; b.chain_up_pub = nullptr; b.chain_down_pub = nullptr; b.chain_up_in = nullptr;
+    b.host_best_hint = nullptr; b.host_best_report = nullptr;
     b.fault_strip = -1;
     b.trace = nullptr;
     int waves = std::min(count, h->waves);

@@ -64,6 +64,15 @@ struct KernelArgs {
     unsigned long long* pruned_slabs;   // device counter of skipped 64-step slabs
     int* dbg;                    // optional debug words (nullptr in production)
     long long* trace;            // optional per-strip timing {start,end,poll spins,first chunk} (nullptr in production)
+    // ---- running best shared along a chain of column bands (T domain like gbest; any value ever stored is the score
+    //      of a real alignment, so a stale or out-of-order word is only a weaker pruning bound) ----
+    // Every word has ONE writer kernel and plain system-scope stores, like the row counter of a column port:
+    const int* chain_down_in;    // own inbound port +64: best known to the bands on the LEFT (the previous band's kernel stores it)
+    int* chain_up_pub;           // own inbound port +128: best known HERE, for the previous band's kernel to read
+    int* chain_down_pub;         // next band's port +64 (peer-mapped): best known here, pushed to the RIGHT
+    const int* chain_up_in;      // next band's port +128 (peer-mapped): what the bands on the right know (remote load)
+    const int* host_best_hint;   // pinned host word: a lower bound from outside (mi355sw_stream_best_hint), or nullptr
+    int* host_best_report;       // pinned host word: the running best as of the last completed strip, or nullptr
 };
 
 // The argument block lives in device memory and is read through the constant address space with a
@@ -138,6 +147,25 @@ static __device__ __attribute__((noinline, unused)) int claim_strip_common(const
     return s;
 }
 
+// Relay of the running best between this kernel, its neighbours in the band chain and the host.  Called by lane 0
+// inside the ordered (hence serialised) section of complete_strip_common: reads every inbound word, folds the
+// maximum into this GPU's gbest and republishes it on every outbound word -- so a score found by any band reaches
+// every other band hop by hop, in both directions, without any kernel ever waiting for it.
+static __device__ __forceinline__ void relay_running_best(const UniformArgs a) {
+    if (a->gbest == nullptr) return;
+    if (a->chain_down_in == nullptr && a->chain_up_in == nullptr && a->chain_down_pub == nullptr && a->chain_up_pub == nullptr &&
+        a->host_best_hint == nullptr && a->host_best_report == nullptr) return;
+    const int v0 = __hip_atomic_load(a->gbest, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int v = v0;
+    if (a->chain_down_in != nullptr) v = max(v, __hip_atomic_load(a->chain_down_in, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+    if (a->chain_up_in != nullptr) v = max(v, __hip_atomic_load(a->chain_up_in, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+    if (a->host_best_hint != nullptr) v = max(v, __hip_atomic_load(a->host_best_hint, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+    if (v > v0) atomicMax(a->gbest, v);
+    if (a->chain_up_pub != nullptr) __hip_atomic_store(a->chain_up_pub, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (a->chain_down_pub != nullptr) __hip_atomic_store(a->chain_down_pub, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (a->host_best_report != nullptr) __hip_atomic_store(a->host_best_report, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // Ordered completion: strips_done == s+1 means strips 0..s are complete and their last-column / special-row /
 // best records are visible (system scope) to the host -- and, through the column port, to the next band's GPU.
 static __device__ __attribute__((noinline, unused)) void complete_strip_common(const KernelArgs* ap, const int s_in, const int lane, const int strip_rows) {
@@ -153,6 +181,7 @@ static __device__ __attribute__((noinline, unused)) void complete_strip_common(c
     }
     if (lane == 0) {
         if (spins >= spin_limit) atomicExch(a->error_flag, 3);
+        relay_running_best(a);
         const int err = __hip_atomic_load(a->error_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (err != 0 && a->host_error != nullptr)
             __hip_atomic_store(a->host_error, err, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);

@@ -92,7 +92,7 @@ class StreamParams(C.Structure):
                 ("special_row_interval", C.c_int32), ("track_best", C.c_int32), ("force_int32", C.c_int32),
                 ("prune_blocks", C.c_int32), ("prune_rows", C.c_int32), ("prune_cols", C.c_int32),
                 ("first_column_port", C.c_int32), ("last_column_port", C.c_int32),
-                ("first_column_resume_rows", C.c_int32)]
+                ("first_column_resume_rows", C.c_int32), ("share_best", C.c_int32)]
 
 
 class Stage4Stats(C.Structure):
@@ -142,6 +142,7 @@ ABI_SYMBOLS = [
     "mi355sw_stream_begin", "mi355sw_stream_feed_column", "mi355sw_stream_poll",
     "mi355sw_stream_read_column", "mi355sw_stream_read_special_row", "mi355sw_stream_read_last_row",
     "mi355sw_stream_abort", "mi355sw_stream_end", "mi355sw_stream_strip_scores",
+    "mi355sw_stream_best_hint", "mi355sw_stream_running_best",
     "mi355sw_port_create", "mi355sw_port_open", "mi355sw_port_attach", "mi355sw_port_reset", "mi355sw_port_rows_ready", "mi355sw_port_read",
     "mi355sw_port_local_pointers", "mi355sw_port_close", "mi355sw_stage4", "mi355sw_free",
     "mi355sw_device_count", "mi355sw_device_info",
@@ -192,6 +193,8 @@ def load_library():
     lib.mi355sw_stream_read_special_row.argtypes = [H, C.c_int32, C.POINTER(C.c_int32), C.c_void_p, C.c_int32, C.c_int32]
     lib.mi355sw_stream_read_last_row.argtypes = [H, C.c_void_p, C.c_int32, C.c_int32]
     lib.mi355sw_stream_abort.argtypes = [H]
+    lib.mi355sw_stream_best_hint.argtypes = [H, C.c_int32]
+    lib.mi355sw_stream_running_best.argtypes = [H, C.POINTER(C.c_int32)]
     lib.mi355sw_stream_end.argtypes = [H, C.POINTER(Score), C.POINTER(C.c_int32)]
     lib.mi355sw_stream_strip_scores.argtypes = [H, C.c_void_p, C.c_int32]
     lib.mi355sw_port_create.argtypes = [H, C.c_int32, C.POINTER(PortHandle)]
@@ -324,7 +327,7 @@ class MI355Aligner:
                     first_column_start_offset=0, stream_first_column=False, first_column=None,
                     want_last_column=False, want_last_row=False, special_row_interval=0, track_best=True,
                     force_int32=False, prune_blocks=False, prune_rows=0, prune_cols=0,
-                    first_column_port=False, last_column_port=False, first_column_resume_rows=0):
+                    first_column_port=False, last_column_port=False, first_column_resume_rows=0, share_best=False):
         sp = StreamParams()
         sp.recurrence_type = recurrence_type
         sp.first_row_init_type, sp.first_row_start_offset = first_row_init_type, first_row_start_offset
@@ -341,6 +344,7 @@ class MI355Aligner:
         sp.prune_blocks, sp.prune_rows, sp.prune_cols = int(prune_blocks), int(prune_rows), int(prune_cols)
         sp.first_column_port, sp.last_column_port = int(first_column_port), int(last_column_port)
         sp.first_column_resume_rows = int(first_column_resume_rows)
+        sp.share_best = int(share_best)
         self._check(self._lib.mi355sw_stream_begin(self._h, C.byref(partition), C.byref(sp)), "streamBegin")
         self._stream_part = partition
 
@@ -376,6 +380,16 @@ class MI355Aligner:
 
     def streamAbort(self):
         self._check(self._lib.mi355sw_stream_abort(self._h), "streamAbort")
+
+    def streamBestHint(self, score):
+        """a score some alignment of the super-partition reaches (found elsewhere): lower bound for block pruning"""
+        self._check(self._lib.mi355sw_stream_best_hint(self._h, int(score)), "streamBestHint")
+
+    def streamRunningBest(self):
+        """best score known to the running kernel at its last strip hand-over (-INF before the first)"""
+        v = C.c_int32()
+        self._check(self._lib.mi355sw_stream_running_best(self._h, C.byref(v)), "streamRunningBest")
+        return v.value
 
     def streamEnd(self):
         s, nsp = Score(), C.c_int32()

@@ -32,6 +32,7 @@ class OracleStreamEngine:
             self.in_shm.close(); self.in_shm.unlink()
         self.in_shm = shared_memory.SharedMemory(create=True, size=256 + 8 * (rows + 1))
         self.in_shm.buf[:256] = bytes(256)
+        np.frombuffer(self.in_shm.buf, dtype=np.int32, count=64)[[16, 32]] = -999999999   # the two running-best words
         ph = PortHandle()
         name = self.in_shm.name.encode()
         for k, b in enumerate(name):
@@ -41,6 +42,7 @@ class OracleStreamEngine:
 
     def portReset(self):
         self.in_shm.buf[:4] = bytes(4)
+        np.frombuffer(self.in_shm.buf, dtype=np.int32, count=64)[[16, 32]] = -999999999
 
     def portOpen(self, ph):
         from multiprocessing import shared_memory
@@ -66,11 +68,25 @@ class OracleStreamEngine:
 
     def streamBegin(self, part, recurrence_type=1, track_best=True, first_row_init_type=0, first_row_start_offset=0,
                     want_last_column=False, first_column_init_type=0, stream_first_column=False, first_column=None,
-                    first_column_port=False, last_column_port=False, **kw):
+                    first_column_port=False, last_column_port=False, special_row_interval=0, prune_blocks=False,
+                    prune_rows=0, prune_cols=0, share_best=False, **kw):
         o = self.o
         self.from_port, self.to_port = first_column_port, last_column_port
+        # special rows every K "strips" (the stand-in's strip = one row segment), never row 0 nor rows >= m
+        self.sp_k = -(-special_row_interval // self.seg) if special_row_interval > 0 else 0
+        self.sp_rows = {}
+        # block pruning as the strip kernel does it: a block (row segment x 128 columns) is skipped when nothing that
+        # enters it can reach the running best -- of this band, or (share_best) of the whole chain; skipped cells
+        # count as H = 0, E = F = -INF
+        self.prune = bool(prune_blocks)
+        self.share = bool(share_best) and not os.environ.get("MI355SW_NO_SHARED_BEST")
+        self.hint = -o.INF
+        self.own_best = -o.INF
+        self.pruned_blocks = self.total_blocks = 0
         self.part, self.rec = part, recurrence_type
         self.m, self.n = part.i1 - part.i0, part.j1 - part.j0
+        self.prune_rows = prune_rows or self.m
+        self.prune_cols = prune_cols or self.n
         self.row = o.initial_cells(first_row_init_type, first_row_start_offset, self.n + 1)
         self.custom_col = first_column_init_type == o.INIT_WITH_CUSTOM_DATA
         self.col = np.zeros((self.m + 1, 2), dtype=np.int32)
@@ -118,6 +134,9 @@ class OracleStreamEngine:
             if self.fed < r1:
                 return
             r0 = self.done
+            if self.prune:
+                self._segment_with_pruning(r0, r1)
+                continue
             res = o.stage1(self.s0[self.part.i0 + r0:self.part.i0 + r1], self.s1[self.part.j0:self.part.j1],
                            recurrence=self.rec, first_row_type=o.INIT_WITH_CUSTOM_DATA, custom_first_row=self.row,
                            first_col_type=o.INIT_WITH_CUSTOM_DATA, custom_first_col=self.col[r0:r1 + 1],
@@ -131,7 +150,80 @@ class OracleStreamEngine:
             b = res["best"]
             if b[0] >= 0:
                 self.cands.append((b[0] - 1 + r0 + self.part.i0, b[1] - 1 + self.part.j0, b[2]))
-            self.done = r1
+                self.own_best = max(self.own_best, b[2])
+            self._segment_done(r1)
+
+    def _segment_done(self, r1):
+        if self.sp_k and (r1 // self.seg) % self.sp_k == 0 and r1 % self.seg == 0 and r1 < self.m:
+            self.sp_rows[r1] = self.row[1:].copy()
+        self._relay()
+        self.done = r1
+
+    def _known(self):
+        return max(self.own_best, self.hint) if self.share else self.own_best
+
+    def _relay(self):
+        """relay_running_best of csrc/sw_kernel.h on the shared-memory ports: +64 pushed by the band on the left, +128
+        published by the owner"""
+        if not self.share:
+            return
+        word = lambda shm, off: np.frombuffer(shm.buf, dtype=np.int32, count=1, offset=off)
+        v = max(self.own_best, self.hint)
+        if self.from_port:
+            v = max(v, int(word(self.in_shm, 64)[0]))
+        if self.to_port:
+            v = max(v, int(word(self.out_shm, 128)[0]))
+        self.hint = max(self.hint, v)
+        if self.from_port:
+            word(self.in_shm, 128)[0] = v
+        if self.to_port:
+            word(self.out_shm, 64)[0] = v
+
+    def _segment_with_pruning(self, r0, r1):
+        o, INF = self.o, self.o.INF
+        i0, i1 = self.part.i0 + r0, self.part.i0 + r1
+        col = self.col[r0:r1 + 1].copy()
+        for j0 in range(0, self.n, 128):
+            j1 = min(j0 + 128, self.n)
+            blk = self.row[1 + j0:1 + j1]
+            self.total_blocks += 1
+            e = max(int(blk[:, 0].max()), int(col[:, 0].max()))
+            left = min(self.prune_rows - r0, self.prune_cols - j0)
+            if self.rec == o.SMITH_WATERMAN and e + left < self._known():
+                diag = int(blk[-1, 0])
+                blk[:, 0], blk[:, 1] = 0, -INF
+                col[0] = (diag, -INF)
+                col[1:, 0], col[1:, 1] = 0, -INF
+                self.pruned_blocks += 1
+                continue
+            b = o.process_block(self.s0, self.s1, blk, col, i0, self.part.j0 + j0, i1, self.part.j0 + j1, self.rec)
+            if b[2] > -INF:
+                self.cands.append(tuple(int(x) for x in b))
+                self.own_best = max(self.own_best, int(b[2]))
+        self.row[0] = (self.col[r1][0], -INF)
+        self.last_col[r0:r1] = col[1:]
+        if self.to_port:
+            dst = np.frombuffer(self.out_shm.buf, dtype=np.int32, count=2 * (r1 - r0), offset=256 + 8 * (r0 + 1)).reshape(-1, 2)
+            dst[:] = col[1:]
+            np.frombuffer(self.out_shm.buf, dtype=np.int32, count=1)[0] = r1
+        self._segment_done(r1)
+
+    def streamReadSpecialRow(self, k, col=0, length=None):
+        from masa_cudalign_amd.engine import AlignerError
+        step = self.sp_k * self.seg
+        if not self.sp_k or k < 0 or (k + 1) * step >= self.m:
+            raise AlignerError("streamReadSpecialRow: EINVAL special row range")
+        dp = (k + 1) * step
+        length = self.n - col if length is None else length
+        if length == 0:
+            return dp, np.empty((0, 2), dtype=np.int32)
+        return dp, self.sp_rows[dp][col:col + length].copy()
+
+    def streamBestHint(self, score):
+        self.hint = max(self.hint, int(score))
+
+    def streamRunningBest(self):
+        return max(self.own_best, self.hint) if self.share else self.own_best
 
     def streamPoll(self):
         self._advance()
@@ -368,3 +460,83 @@ def test_global_nw_bands_over_gloo(pkg, oracle):
         assert np.array_equal(res[rank], ref["last_col"][1:]), rank
     full = oracle.stage1(s0, s1, **kw)
     assert int(res[world - 1][-1, 0]) == full["best"][2]
+
+
+def _worker_prune(rank, world, port, m, n, transport, q):
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as graft
+    pkg = graft.load_package()
+    oracle = graft.load_oracle()
+    from masa_cudalign_amd.bands import BandRunner, band_limits
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        s0, s1 = pkg.seqgen.related_pair(m, n, cfg=41)
+        lim = band_limits(n, [1] * world)
+        out = {}
+        for mode in ("plain", "pruned", "pruned_alone"):
+            # "pruned_alone": every band prunes against its own best only (what a chain without sharing could do)
+            if mode == "pruned_alone":
+                os.environ["MI355SW_NO_SHARED_BEST"] = "1"
+            eng = OracleStreamEngine(oracle, s0, s1, seg=256)   # strip heights are multiples of 256, as the engine's
+            runner = BandRunner(eng, dist=dist, rank=rank, world=world, device=None, segment_rows=300, transport=transport,
+                                prune_blocks=(mode != "plain"))
+            if transport == "p2p":
+                assert runner.probe_p2p(m)
+            rows = {}
+            best = runner.run(m, lim[rank], lim[rank + 1], special_row_interval=512, n_total=n,
+                              special_row_sink=lambda dp, c0, cells: rows.__setitem__(dp, (c0.copy(), cells.copy())))
+            out[mode] = dict(best=tuple(runner.reduce_best(best)), rows=rows, pruned=eng.pruned_blocks, total=eng.total_blocks,
+                             hints=runner.hints, special=list(runner.special_rows))
+            dist.barrier()
+            eng.portClose()
+            os.environ.pop("MI355SW_NO_SHARED_BEST", None)
+        q.put((rank, out))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("transport", ["host", "p2p"])
+def test_bands_prune_with_the_chain_wide_best_and_keep_special_rows(pkg, oracle, transport):
+    """Block pruning over a chain of bands (the reference switches it off when it forks, libmasa.cpp:1318-1321) and one
+    special-rows slice per band (the reference: one area per forked node).  Unpruned: the concatenated slices ARE the
+    single partition's special rows.  Pruned: same best cell, every band past the first prunes, the rows are lower
+    bounds with the same maximum -- and sharing the best along the chain prunes more than every band on its own."""
+    m, n, world = 1500, 1800, 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_prune, args=(r, world, port, m, n, transport, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=240) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    s0, s1 = pkg.seqgen.related_pair(m, n, cfg=41)
+    ref = oracle.stage1(s0, s1)
+    want = (ref["best"][0] - 1, ref["best"][1] - 1, ref["best"][2])
+    for mode in ("plain", "pruned", "pruned_alone"):
+        assert all(res[r][mode]["best"] == want for r in range(world)), mode
+        assert all(res[r][mode]["special"] == [512, 1024] for r in range(world)), mode
+    for dp in (512, 1024):
+        row = oracle.stage1(s0[:dp], s1, want_last_row=True)["last_row"]      # cell 0 = first-column cell, f = -INF
+        for mode in ("plain", "pruned"):
+            got = np.concatenate([res[r][mode]["rows"][dp][1] for r in range(world)])
+            if mode == "plain":
+                assert np.array_equal(got, row[1:]), dp
+                from masa_cudalign_amd.bands import band_limits
+                lim = band_limits(n, [1] * world)
+                for r in range(world):       # leading cell of each slice = the boundary column's cell of that row
+                    assert tuple(res[r][mode]["rows"][dp][0]) == (int(row[lim[r], 0]), -oracle.INF), (dp, r)
+            else:
+                assert np.all(got[:, 0] <= row[1:, 0]) and got[:, 0].max() == row[1:, 0].max(), dp
+    assert all(res[r]["plain"]["pruned"] == 0 for r in range(world))
+    assert all(res[r]["pruned"]["pruned"] > 0 for r in range(1, world))
+    shared = sum(res[r]["pruned"]["pruned"] for r in range(world))
+    alone = sum(res[r]["pruned_alone"]["pruned"] for r in range(world))
+    assert shared > alone, (shared, alone)
+    if transport == "host":                      # the side thread delivered somebody else's best at least once
+        assert sum(res[r]["pruned"]["hints"] for r in range(world)) > 0

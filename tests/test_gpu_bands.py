@@ -151,3 +151,133 @@ def test_port_chain_in_one_process(pkg):
         finally:
             for al in als:
                 al.close()
+
+
+def _worker_prune(rank, world, port, m, n, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    import __graft_entry__ as graft
+    pkg = graft.load_package()
+    from masa_cudalign_amd.bands import BandRunner, band_limits
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        s0, s1 = pkg.seqgen.related_pair(m, n, cfg=47)
+        lim = band_limits(n, [1] * world)
+        out = {}
+        for mode, transport in (("plain", "p2p"), ("pruned", "p2p"), ("pruned_host", "host")):
+            al = pkg.MI355Aligner(device=0, rows_per_lane=4)
+            al.setSequences(s0, s1)
+            runner = BandRunner(al, dist=dist, rank=rank, world=world, device=None, segment_rows=2048, transport=transport,
+                                prune_blocks=(mode != "plain"))
+            rows = {}
+            best = runner.run(m, lim[rank], lim[rank + 1], special_row_interval=8192, n_total=n,
+                              special_row_sink=lambda dp, c0, cells: rows.__setitem__(dp, (c0.copy(), cells.copy())))
+            st = al.getStatistics()
+            out[mode] = dict(best=tuple(runner.reduce_best(best)), rows=rows, pruned=int(st["pruned_cells"]),
+                             cells=int(st["cells"]), hints=runner.hints, special=list(runner.special_rows))
+            dist.barrier()
+            al.close()
+        q.put((rank, out))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_chain_of_bands_prunes_with_the_shared_best_and_keeps_special_rows(pkg, oracle):
+    """Four bands in four processes (one GPU, ports mapped with hipIpc), a related pair: block pruning ON in every
+    band against the running best of the whole chain (the reference switches pruning off when it forks,
+    M/libmasa/libmasa.cpp:1318-1321) and one special-rows slice per band (the reference: one area per forked node,
+    Job.cpp:123-128).  Without pruning the concatenated slices are the single partition's special rows, cell for cell;
+    with pruning the chain reports the same best cell, every band past the first skips cells, and the rows are lower
+    bounds of the exact ones with the same maximum.  Both transports."""
+    import numpy as np
+    from masa_cudalign_amd.bands import band_limits
+    m, n, world = 36000, 40000, 4
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_prune, args=(r, world, port, m, n, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=800) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    s0, s1 = pkg.seqgen.related_pair(m, n, cfg=47)
+    ref = oracle.stage1(s0, s1)
+    want = (ref["best"][0] - 1, ref["best"][1] - 1, ref["best"][2])
+    lim = band_limits(n, [1] * world)
+    dps = [8192, 16384, 24576, 32768]
+    for mode in ("plain", "pruned", "pruned_host"):
+        assert all(res[r][mode]["best"] == want for r in range(world)), (mode, [res[r][mode]["best"] for r in range(world)], want)
+        assert all(res[r][mode]["special"] == dps for r in range(world)), mode
+    for dp in dps:
+        row = oracle.stage1(s0[:dp], s1, want_last_row=True)["last_row"]
+        got = np.concatenate([res[r]["plain"]["rows"][dp][1] for r in range(world)])
+        assert np.array_equal(got, row[1:]), dp
+        for r in range(world):
+            assert tuple(int(x) for x in res[r]["plain"]["rows"][dp][0]) == (int(row[lim[r], 0]), -oracle.INF), (dp, r)
+        for mode in ("pruned", "pruned_host"):
+            got = np.concatenate([res[r][mode]["rows"][dp][1] for r in range(world)])
+            assert np.all(got[:, 0] <= row[1:, 0]) and got[:, 0].max() == row[1:, 0].max(), (mode, dp)
+    assert all(res[r]["plain"]["pruned"] == 0 for r in range(world))
+    for mode in ("pruned", "pruned_host"):
+        assert all(res[r][mode]["pruned"] > 0 for r in range(1, world)), (mode, [res[r][mode]["pruned"] for r in range(world)])
+    print("pruned fraction per band: p2p %s host %s (hints %s)" % (
+        ["%.2f" % (res[r]["pruned"]["pruned"] / res[r]["pruned"]["cells"]) for r in range(world)],
+        ["%.2f" % (res[r]["pruned_host"]["pruned"] / res[r]["pruned_host"]["cells"]) for r in range(world)],
+        [res[r]["pruned_host"]["hints"] for r in range(world)]))
+
+
+def test_running_best_travels_through_the_ports_in_both_directions(pkg, oracle):
+    """The two running-best words of a column port, deterministically: two bands in ONE process run one after the other.
+    (1) band 1 starts when band 0 is through, so band 0's final best is waiting in band 1's port (pushed DOWN the
+    chain): band 1 skips more cells than the same band pruning on its own (MI355SW_NO_SHARED_BEST).  (2) band 0 run
+    again WITHOUT a port reset reads what band 1 published (UP the chain) -- the best of the same matrix, so a valid
+    bound -- and skips more than it did the first time.  Best cells unchanged throughout."""
+    from masa_cudalign_amd.bands import band_limits, canonical_best
+    m, n = 30000, 32000
+    s0, s1 = pkg.seqgen.related_pair(m, n, cfg=48)
+    ref = oracle.stage1(s0, s1)
+    want = (ref["best"][0] - 1, ref["best"][1] - 1, ref["best"][2])
+    lim = band_limits(n, [1, 1])
+
+    def run_band(al, k, shared):
+        if shared:
+            os.environ.pop("MI355SW_NO_SHARED_BEST", None)
+        else:
+            os.environ["MI355SW_NO_SHARED_BEST"] = "1"
+        try:
+            kw = dict(prune_blocks=True, prune_rows=m, prune_cols=n - lim[k], share_best=True, last_column_port=(k == 0))
+            if k == 1:
+                corner = [[0, -pkg.INF]]
+                kw.update(first_column_init_type=pkg.INIT_WITH_CUSTOM_DATA, first_column_port=True, first_column=corner)
+            al.streamBegin(pkg.Partition(0, lim[k], m, lim[k + 1]), **kw)
+            while not al.streamPoll()[1]:
+                pass
+            best, _ = al.streamEnd()
+            return best, int(al.getStatistics()["pruned_cells"])
+        finally:
+            os.environ.pop("MI355SW_NO_SHARED_BEST", None)
+
+    res = {}
+    for shared in (False, True):
+        a0, a1 = pkg.MI355Aligner(device=0, rows_per_lane=4), pkg.MI355Aligner(device=0, rows_per_lane=4)
+        try:
+            for al in (a0, a1):
+                al.setSequences(s0, s1)
+            a1.portCreate(m)
+            a0.portAttach(a1)
+            b0, p0 = run_band(a0, 0, shared)
+            b1, p1 = run_band(a1, 1, shared)
+            assert canonical_best([b0, b1]) == want
+            b0b, p0b = run_band(a0, 0, shared)          # the port still holds what band 1 published
+            assert b0b == b0
+            res[shared] = (p0, p1, p0b)
+        finally:
+            a0.close(); a1.close()
+    print("pruned cells (band 0, band 1, band 0 again): alone %s shared %s" % (res[False], res[True]))
+    assert res[True][1] > res[False][1]                  # down the chain
+    assert res[True][2] > res[True][0]                   # up the chain

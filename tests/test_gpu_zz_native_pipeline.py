@@ -6,11 +6,9 @@ The same drivers are pinned on the CPU against MASA-Core byte for byte (tests/te
 double); the same engine calls are made by MASA-Core's own stages 2-3 in tests/test_gpu_dropin.py.  What is new here is
 the combination -- the Python AlignerManager as the engine's callback table.
 
-WRITTEN AT THE END OF ROUND 2 WITH NO GPU MINUTES LEFT: nothing in this file had run on an MI355X when it was
-committed.  Until it has been green once on hardware, every case runs in a CHILD process with a time limit
-(tests/native_pipeline_cases.py), and a case that does not hold is reported as XFAIL with the child's output instead
-of failing the session -- a pass is a real pass.  MI355SW_NATIVE_PIPELINE=1 makes failures count (what round 3 sets
-once the cases are green, before this paragraph is deleted).  The file sorts last."""
+First green on an MI355X in round 3 (gpurun_out/r03 -> profiles/r03_native_pipeline_*): every case counts.  Each case
+still runs in a CHILD process with a time limit (tests/native_pipeline_cases.py), so that a hang is a failure with the
+child's output, not a stuck session.  The file sorts last."""
 import json
 import os
 import subprocess
@@ -21,27 +19,17 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-STRICT = os.environ.get("MI355SW_NATIVE_PIPELINE") == "1"
-
-
-_timed_out = []
 
 
 def _case(name, limit_s=180):
-    if _timed_out and not STRICT:                         # one hang is evidence enough: do not spend the session on more
-        pytest.xfail("case %s timed out before; %s not started" % (_timed_out[0], name))
     try:
         p = subprocess.run([sys.executable, os.path.join(HERE, "native_pipeline_cases.py"), name], stdout=subprocess.PIPE,
                            stderr=subprocess.STDOUT, timeout=limit_s)
         rc, log = p.returncode, p.stdout.decode(errors="replace")
     except subprocess.TimeoutExpired as e:
-        _timed_out.append(name)
         rc, log = -1, "timed out after %d s\n%s" % (limit_s, (e.stdout or b"").decode(errors="replace"))
     if rc != 0:
-        msg = "native pipeline case %s: exit code %d\n%s" % (name, rc, log[-3000:])
-        if STRICT:
-            pytest.fail(msg)
-        pytest.xfail("first hardware run of the native stages 2-3 (see the file's header): " + msg)
+        pytest.fail("native pipeline case %s: exit code %d\n%s" % (name, rc, log[-3000:]))
     res = json.loads([ln for ln in log.splitlines() if ln.startswith("{")][-1])
     assert res["ok"] and all(res["checks"].values()), res
     return res

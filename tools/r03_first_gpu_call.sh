@@ -10,7 +10,7 @@ export MI355SW_NATIVE_PIPELINE=1
 timeout 900 python -m pytest tests/test_gpu_zz_native_pipeline.py -q > gpurun_out/r03/native_pipeline_tests.log 2>&1
 echo "pytest rc=$?" >> gpurun_out/r03/native_pipeline_tests.log
 tail -5 gpurun_out/r03/native_pipeline_tests.log
-timeout 400 python tools/native_pipeline_run.py 10000000 10000000 - gpurun_out/r03/native_pipeline_10Mx10M.json > gpurun_out/r03/native_pipeline_10Mx10M.log 2>&1
+timeout 700 python tools/native_pipeline_run.py 10000000 10000000 - gpurun_out/r03/native_pipeline_10Mx10M.json > gpurun_out/r03/native_pipeline_10Mx10M.log 2>&1
 echo "native 10Mx10M rc=$?"
 tail -2 gpurun_out/r03/native_pipeline_10Mx10M.log
 MI355SW_BENCH_REHEARSAL=1 timeout 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 \
