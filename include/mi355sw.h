@@ -66,6 +66,15 @@ typedef struct {
     int32_t waves;           /* persistent wavefronts (reference: --blocks); 0 = one per SIMD      */
     int32_t flags;           /* MI355SW_F_*                                                          */
     int64_t max_special_bytes; /* HBM budget for device-resident special rows, 0 = 60 % of the HBM free at stream_begin */
+    int32_t block_score_columns; /* > 0: mi355sw_align_partition also reports the best cell of every BLOCK of its grid
+                                    through dispatch_score(score, bx, by) -- block (bx, by) = rows of strip `by` x columns
+                                    [j0 + bx*W, j0 + (bx+1)*W), W = this value (Grid::setBlockHeight / setBlockWidth,
+                                    M/libmasa/Grid.cpp:52-68).  Reference: CUDAligner::getBlockScores +
+                                    AbstractDiagonalAligner::flushBlockScores (X/CUDAligner.cpp:441-452,
+                                    AbstractDiagonalAligner.cpp:392-403); its only consumer is --dump-blocks
+                                    (AlignerManager.cpp:418-423, BlocksFile.cpp).  Costs a second sweep of the
+                                    partition, as a chain of W-column bands.  0 = off. */
+    int32_t reserved_;
 } mi355sw_config;
 #define MI355SW_F_FORCE_GENERIC_COMPARE 1   /* raw byte compare kernels even if a profile fits */
 #define MI355SW_F_FORCE_INT32 2             /* never use the packed 16-bit SW kernel */

@@ -255,7 +255,18 @@ class BandRunner:
                       stream_first_column=not p2p, first_column_port=p2p)
         if p2p:
             self._exchange_ports(m)
+        # Ordered start: band g+1 launches its kernel only after band g has launched its own.  It could do nothing
+        # before band g's first strip is through anyway, and where bands SHARE a GPU (tests and rehearsals on a
+        # one-GPU box) a kernel that sits polling for its neighbour has been seen to keep that neighbour's set-up
+        # work (fills, the seed pass) off the GPU for tens of seconds.
+        if not first and dist is not None:
+            import torch
+            go = torch.zeros(1, dtype=torch.uint8)
+            dist.recv(go, src=self.rank - 1)
         eng.streamBegin(part, **kw)
+        if not last and dist is not None:
+            import torch
+            dist.send(torch.ones(1, dtype=torch.uint8), dst=self.rank + 1)
         self.restarts = 0
 
         lock = threading.Lock()          # the engine handle is driven by one thread at a time

@@ -100,6 +100,7 @@ struct mi355sw_handle {
     mi355sw_stats stats{};
     std::atomic<long long> processed_total{0};
     int abort_strips = -1;          // host stop: strips complete or in flight at that moment (the rest were skipped)
+    bool exact_records = false;     // every strip record must carry its cell (block-score pass): no two-phase tracking
     std::atomic<int> prog_strips{0}, prog_total{0};
 };
 
@@ -235,7 +236,7 @@ int mi355sw_get_capabilities(mi355sw_handle* h, mi355sw_capabilities* c) {
     // no texture limit on MI355X => no maximum sequence length (M/stage1/sw_stage1.cpp:362-375)
     c->dispatch_last_cell = 1; c->dispatch_last_row = 1; c->dispatch_last_column = 1;
     c->dispatch_special_row = 1; c->dispatch_special_column = 0;
-    c->dispatch_scores = 1; c->dispatch_block_scores = 0; c->dispatch_best_score = 1;
+    c->dispatch_scores = 1; c->dispatch_block_scores = 1; c->dispatch_best_score = 1;   // block scores: config.block_score_columns
     c->customize_first_row = 1; c->customize_first_column = 1;
     c->process_partition = 1; c->variable_penalties = 0; c->block_pruning = 1;
     c->needleman_wunsch = 1; c->smith_waterman = 1; c->fork_processes = 1;
@@ -341,8 +342,10 @@ static int pick_rows_per_lane(const mi355sw_handle* h, int m, int n, bool packed
     // continued or read by a run of the reference and vice versa; 768- and 1536-row strips are only chosen when no
     // special rows are asked for (they are 1-2 % faster on some shapes).
     static const int cand16[] = {4, 8, 12, 16, 24, 32}, cand32[] = {4, 8, 16}, cand16p2[] = {4, 8, 16, 32};
-    const int* cand = packed ? (special_rows ? cand16p2 : cand16) : cand32;
-    const int nc = packed ? (special_rows ? 4 : 6) : 3;
+    // block scores: the grid's block height is the strip height, and it must survive a rerun on the int32 kernels
+    const bool common_heights = !packed || h->cfg.block_score_columns > 0;
+    const int* cand = common_heights ? cand32 : (special_rows ? cand16p2 : cand16);
+    const int nc = common_heights ? 3 : (special_rows ? 4 : 6);
     const int W = h->cfg.waves > 0 ? h->cfg.waves : h->compute_units * 4;
     int best = cand[0];
     double tb = estimate_ns(m, n, best, W);
@@ -408,7 +411,7 @@ int mi355sw_stream_begin(mi355sw_handle* h, const mi355sw_partition* part, const
     // The exact pass costs one strip sweep (n steps of a short pipeline); it pays off once the main pass
     // is hundreds of sweeps long.  Smaller partitions keep exact tracking in the main pass, seeded with the
     // running global best so that it stays off the start-up path.
-    h->two_phase = h->use16 && p->track_best && (m >= (32 << 20) || getenv("MI355SW_TWO_PHASE"));
+    h->two_phase = h->use16 && p->track_best && !h->exact_records && (m >= (32 << 20) || getenv("MI355SW_TWO_PHASE"));
     h->ckpt_interval = 0; h->n_ckpt = 0; h->ckpt_pitch = h->special_pitch;
     if (h->two_phase) {
         const int64_t budget = h->cfg.max_special_bytes > 0 ? h->cfg.max_special_bytes : (8LL << 30);   // checkpoints: 64 rows at most
@@ -522,7 +525,7 @@ int mi355sw_stream_begin(mi355sw_handle* h, const mi355sw_partition* part, const
     HIPCHK(h, hipMemsetAsync(h->d_progress.p, 0, sizeof(int) * ((size_t) h->strips + 1), h->stream));
     HIPCHK(h, launch_fill_int((int*) h->d_progress.p, 1, n, h->stream));   // virtual strip above: all columns ready
     HIPCHK(h, hipMemsetAsync(h->d_ctrl.p, 0, 256, h->stream));
-    HIPCHK(h, launch_fill_int((int*) h->d_ctrl.p + 52, 1, -MI355SW_INF, h->stream));   // running global best
+    HIPCHK(h, launch_fill_int((int*) h->d_ctrl.p + 52, 2, -MI355SW_INF, h->stream));   // running global best (+ its never-written twin)
     HIPCHK(h, hipMemsetAsync(h->d_strip_best.p, 0, sizeof(int4) * (size_t) h->strips, h->stream));
     h->h_pinned[0] = 0;
 
@@ -571,6 +574,7 @@ int mi355sw_stream_begin(mi355sw_handle* h, const mi355sw_partition* part, const
     h->abort_strips = -1;
     a.host_abort = h->h_pinned + 32;
     a.gbest = ctrl + 52;
+    a.gbest_in = h->exact_records ? ctrl + 53 : ctrl + 52;
     // block pruning: packed SW kernel only (the int32 fallback and NW simply compute everything)
     a.prune = (p->prune_blocks && h->use16 && p->recurrence_type == MI355SW_SMITH_WATERMAN) ? 1 : 0;
     a.prune_rows = p->prune_rows > 0 ? p->prune_rows : m;
@@ -616,7 +620,7 @@ int mi355sw_stream_begin(mi355sw_handle* h, const mi355sw_partition* part, const
     // just written: either way a lower bound of the true cells, so every score it sees is the score of a
     // real local alignment) and publish the maximum; 0.5 ms for ~3e9 cells.
     if (h->use16 && p->recurrence_type == MI355SW_SMITH_WATERMAN && p->track_best && !h->two_phase &&
-        h->strips >= 64 && n >= 16384 && !getenv("MI355SW_NOSEED")) {
+        h->strips >= 64 && n >= 16384 && !h->exact_records && !getenv("MI355SW_NOSEED")) {
         const int SEED_COLS = 2048;
         const int ws = std::min(h->strips, waves);
         // layout of the seed pass's scratch: [argument block | control words | progress | strip records | bus]
@@ -909,7 +913,7 @@ static int run_exact_pass(mi355sw_handle* h, int s_star, int want_score, mi355sw
     HIPCHK(h, hipMemsetAsync(h->d_progress.p, 0, sizeof(int) * ((size_t) count + 1), h->stream));
     HIPCHK(h, launch_fill_int((int*) h->d_progress.p, 1, h->n, h->stream));
     HIPCHK(h, hipMemsetAsync(h->d_ctrl.p, 0, 256, h->stream));
-    HIPCHK(h, launch_fill_int((int*) h->d_ctrl.p + 52, 1, -MI355SW_INF, h->stream));
+    HIPCHK(h, launch_fill_int((int*) h->d_ctrl.p + 52, 2, -MI355SW_INF, h->stream));
     HIPCHK(h, hipMemsetAsync(h->d_strip_best.p, 0, sizeof(int4) * (size_t) count, h->stream));
     h->h_pinned[0] = 0;
     KernelArgs b = h->kargs;
@@ -1066,6 +1070,72 @@ static int flush_strip_scores(mi355sw_handle* h, const mi355sw_partition* part, 
     }
     *rows_sent = (int) std::min<long long>((long long) upto_strip * h->SH, h->m);
     return MI355SW_OK;
+}
+
+// Block scores (config.block_score_columns = W > 0): the best cell of every block of the grid "strip x W columns",
+// reported as dispatch_score(score, bx, by) -- what CUDAligner::getBlockScores + AbstractDiagonalAligner::
+// flushBlockScores deliver (X/CUDAligner.cpp:441-452, AbstractDiagonalAligner.cpp:392-403; consumer: --dump-blocks).
+// The strip kernel keeps ONE canonical best per strip, so the partition is swept once more as a chain of W-column
+// bands -- band bx's per-strip records ARE the records of the blocks (bx, by) -- each band taking the last column of
+// the band before it as its first column.  Exact rectangles, exact canonical cells, no pruning.
+static int block_scores_pass(mi355sw_handle* h, const mi355sw_partition* part, const mi355sw_manager* mg, void* user,
+                             int recurrence, const std::vector<mi355sw_cell>& row_host, bool custom_col, int rows_per_lane) {
+    const int W = h->cfg.block_score_columns;
+    const int m = part->i1 - part->i0, n = part->j1 - part->j0;
+    const int B = (n + W - 1) / W;
+    std::vector<mi355sw_cell> colbuf((size_t) m + 1), firstcol;
+    if (custom_col) firstcol.assign((const mi355sw_cell*) h->p_first_col.p, (const mi355sw_cell*) h->p_first_col.p + m + 1);
+    const mi355sw_stats main_stats = h->stats;
+    const int saved_R = h->cfg.rows_per_lane;
+    h->cfg.rows_per_lane = rows_per_lane;          // same grid rows as the main pass
+    h->exact_records = true;
+    double extra_ms = 0;
+    int rc = MI355SW_OK, launches = 0;
+    for (int bx = 0; bx < B && rc == MI355SW_OK; bx++) {
+        mi355sw_partition bp = {part->i0, part->j0 + bx * W, part->i1, std::min(part->j0 + (bx + 1) * W, part->j1)};
+        for (int attempt = 0; attempt < 2; attempt++) {
+            mi355sw_stream_params sp{};
+            sp.recurrence_type = recurrence;
+            sp.track_best = 1;
+            sp.force_int32 = attempt;
+            if (!row_host.empty()) { sp.first_row_init_type = MI355SW_INIT_WITH_CUSTOM_DATA; sp.first_row = row_host.data() + (bp.j0 - part->j0); }
+            if (bx == 0) {
+                if (custom_col) { sp.first_column_init_type = MI355SW_INIT_WITH_CUSTOM_DATA; sp.first_column = firstcol.data(); }
+            } else {
+                colbuf[0].h = row_host.empty() ? 0 : row_host[(size_t) (bp.j0 - part->j0)].h;   // H(i0, band's first column - 1)
+                colbuf[0].f = -MI355SW_INF;
+                sp.first_column_init_type = MI355SW_INIT_WITH_CUSTOM_DATA;
+                sp.first_column = colbuf.data();
+            }
+            sp.want_last_column = bx < B - 1;
+            if ((rc = mi355sw_stream_begin(h, &bp, &sp))) break;
+            hipError_t e = hipStreamSynchronize(h->stream);
+            int rows_done = 0, fin = 0;
+            rc = (e == hipSuccess) ? mi355sw_stream_poll(h, &rows_done, &fin) : MI355SW_EHIP;
+            if (!rc && sp.want_last_column) rc = mi355sw_stream_read_column(h, 0, colbuf.data() + 1, m);
+            mi355sw_score b;
+            const int rc2 = mi355sw_stream_end(h, &b, nullptr);
+            if (!rc) rc = rc2;
+            extra_ms += h->stats.kernel_ms;
+            launches += h->stats.kernel_launches;
+            if (rc == MI355SW_EOVERFLOW16 && attempt == 0) { rc = MI355SW_OK; continue; }
+            break;
+        }
+        if (rc) break;
+        for (int s = 0; s < h->strips; s++) {
+            const int4 r = h->strip_best_host[(size_t) s];
+            mi355sw_score sc;
+            if (r.w == 1 && r.z >= 0) { sc.score = r.x; sc.i = r.y + bp.i0; sc.j = r.z + bp.j0; }
+            else { sc.score = -MI355SW_INF; sc.i = -1; sc.j = -1; }
+            mg->dispatch_score(user, sc, bx, s);
+        }
+    }
+    h->cfg.rows_per_lane = saved_R;
+    h->exact_records = false;
+    h->stats = main_stats;
+    h->stats.kernel_ms += extra_ms;
+    h->stats.kernel_launches += launches;
+    return rc;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1268,6 +1338,8 @@ int mi355sw_align_partition(mi355sw_handle* h, const mi355sw_partition* part, co
         s.i = part->i1 - 1; s.j = part->j1 - 1; s.score = lastrow[(size_t) n - 1].h;
         mg->dispatch_score(user, s, -1, -1);
     }
+    if (h->cfg.block_score_columns > 0 && want_scores)
+        return block_scores_pass(h, part, mg, user, sp.recurrence_type, row_host, orig_col_type != MI355SW_INIT_WITH_ZEROES, h->R);
     return MI355SW_OK;
     }   // attempt
     return rc;

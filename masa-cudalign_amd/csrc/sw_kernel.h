@@ -73,6 +73,9 @@ struct KernelArgs {
     const int* chain_up_in;      // next band's port +128 (peer-mapped): what the bands on the right know (remote load)
     const int* host_best_hint;   // pinned host word: a lower bound from outside (mi355sw_stream_best_hint), or nullptr
     int* host_best_report;       // pinned host word: the running best as of the last completed strip, or nullptr
+    const int* gbest_in;         // where the strips READ the running best from: gbest itself, or a word that stays at -INF
+                                 // when every strip record must be that strip's own exact best (block scores) instead
+                                 // of "nothing below what is already known elsewhere"
 };
 
 // The argument block lives in device memory and is read through the constant address space with a

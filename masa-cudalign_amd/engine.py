@@ -60,7 +60,8 @@ class Partition(C.Structure):
 
 class Config(C.Structure):
     _fields_ = [("device", C.c_int32), ("rows_per_lane", C.c_int32), ("waves", C.c_int32),
-                ("flags", C.c_int32), ("max_special_bytes", C.c_int64)]
+                ("flags", C.c_int32), ("max_special_bytes", C.c_int64), ("block_score_columns", C.c_int32),
+                ("reserved_", C.c_int32)]
 
 
 class Capabilities(C.Structure):
@@ -232,10 +233,10 @@ def _cells(a):
 class MI355Aligner:
     """Python mirror of the IAligner a MASA extension implements (M/libmasa/IAligner.hpp)."""
 
-    def __init__(self, device=-1, rows_per_lane=0, waves=0, flags=0, max_special_bytes=0):
+    def __init__(self, device=-1, rows_per_lane=0, waves=0, flags=0, max_special_bytes=0, block_score_columns=0):
         self._lib = load_library()
         self._h = C.c_void_p()
-        cfg = Config(device, rows_per_lane, waves, flags, max_special_bytes)
+        cfg = Config(device, rows_per_lane, waves, flags, max_special_bytes, block_score_columns, 0)
         rc = self._lib.mi355sw_create(C.byref(cfg), C.byref(self._h))
         if rc != 0:
             self._h = C.c_void_p()

@@ -94,6 +94,16 @@ void Mi355Aligner::initialize() {
     config.device = params->getGPU();
     if (params->getWaves() > 0) config.waves = params->getWaves();
     if (params->getStripRows() > 0) config.rows_per_lane = params->getStripRows() / 64;
+    if (params->getBlockColumns() > 0) {
+        // the grid MASA-Core asks for (AlignerManager::dispatchScore -> BlocksFile::initialize(getGrid())) must be
+        // known before the engine has picked anything: fixed strip height, one all three kernel families have
+        const int sr = params->getStripRows();
+        if (sr != 256 && sr != 512 && sr != 1024) {
+            fprintf(stderr, "Mi355Aligner: --block-columns needs --strip-rows=256, 512 or 1024.\n");
+            exit(2);
+        }
+        config.block_score_columns = params->getBlockColumns();
+    }
     check(mi355sw_create(&config, &handle), "mi355sw_create");
 }
 
@@ -111,7 +121,11 @@ void Mi355Aligner::unsetSequences() {
 }
 
 void Mi355Aligner::alignPartition(Partition partition) {
-    createGrid(partition);   // AlignerManager may ask for getGrid() (blocks file)
+    Grid* grid = createGrid(partition);   // AlignerManager asks for getGrid() when it keeps a blocks file (--dump-blocks)
+    if (params->getBlockColumns() > 0) {
+        grid->setBlockHeight(params->getStripRows());
+        grid->setBlockWidth(params->getBlockColumns());
+    }
     mi355sw_manager m;
     m.get_recurrence_type = cbRecurrence;
     m.get_special_row_interval = cbSpecialInterval;

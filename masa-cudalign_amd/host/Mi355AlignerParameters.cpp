@@ -20,22 +20,27 @@
                            (default: picked per partition by the engine's cost model).\n\
                            Special rows fall on multiples of the strip height; use 1024 or\n\
                            2048 to share a special-rows area with CUDAlign (8192 spacing).\n\
+--block-columns=W       Also report the best score of every block of the grid\n\
+                           (strip x W columns), as MASA-Core's --dump-blocks wants them;\n\
+                           needs --strip-rows=256, 512 or 1024 and costs a second sweep.\n\
 "
 
 #define ARG_GPU        0x1001
 #define ARG_LIST_GPUS  0x1002
 #define ARG_BLOCKS     0x1003
 #define ARG_STRIP_ROWS 0x1004
+#define ARG_BLOCK_COLUMNS 0x1005
 
 static struct option long_options[] = {
     {"gpu",        required_argument, 0, ARG_GPU},
     {"list-gpus",  no_argument,       0, ARG_LIST_GPUS},
     {"blocks",     required_argument, 0, ARG_BLOCKS},
     {"strip-rows", required_argument, 0, ARG_STRIP_ROWS},
+    {"block-columns", required_argument, 0, ARG_BLOCK_COLUMNS},
     {0, 0, 0, 0}
 };
 
-Mi355AlignerParameters::Mi355AlignerParameters() : gpu(MI355_DETECT_FASTEST_GPU), waves(0), stripRows(0) {}
+Mi355AlignerParameters::Mi355AlignerParameters() : gpu(MI355_DETECT_FASTEST_GPU), waves(0), stripRows(0), blockColumns(0) {}
 Mi355AlignerParameters::~Mi355AlignerParameters() {}
 
 void Mi355AlignerParameters::printUsage() const {
@@ -124,6 +129,12 @@ int Mi355AlignerParameters::processArgument(int argc, char** argv) {
         if (optarg != NULL) sscanf(optarg, "%d", &stripRows);
         if (stripRows != 256 && stripRows != 512 && stripRows != 768 && stripRows != 1024 && stripRows != 1536 && stripRows != 2048) {
             setLastError("Strip rows must be one of 256, 512, 768, 1024, 1536, 2048.");
+            return -1;
+        }
+        break;
+    case ARG_BLOCK_COLUMNS:
+        if (optarg == NULL || sscanf(optarg, "%d", &blockColumns) != 1 || blockColumns < 1) {
+            setLastError("--block-columns needs a positive number of columns.");
             return -1;
         }
         break;

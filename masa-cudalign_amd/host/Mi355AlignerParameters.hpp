@@ -21,12 +21,13 @@ public:
     void setGPU(int g) { gpu = g; }
     int getWaves() const { return waves; }            /* --blocks: strip wavefronts per launch, 0 = one per SIMD */
     int getStripRows() const { return stripRows; }    /* --strip-rows: 256..2048, 0 = cost model */
+    int getBlockColumns() const { return blockColumns; }   /* --block-columns: width of the blocks whose scores are dispatched, 0 = none */
     static void printGPUDevices(FILE* file);          /* --list-gpus (X/cuda_util.cpp:191-230) */
     static int fastestGPU();                          /* X/cuda_util.cpp:238-287: largest CUs x clock */
     static int deviceWeights(int* weights, int max);  /* X/cuda_util.cpp:191-257: per-GPU weights, asked from a child process */
 
 private:
-    int gpu, waves, stripRows;
+    int gpu, waves, stripRows, blockColumns;
 };
 
 #endif

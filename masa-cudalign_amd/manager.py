@@ -329,6 +329,10 @@ class Stage1Manager:
         i, j, s = score
         i += self.seq0_offset + 1      # AlignerManager.cpp:412-415: cell index -> 1-based DP coordinate
         j += self.seq1_offset + 1
+        if bx != -1 and by != -1:      # :418-423: what --dump-blocks stores (BlocksFile::setScore)
+            if getattr(self, "block_scores", None) is None:
+                self.block_scores = {}
+            self.block_scores[(bx, by)] = (i, j, s)
         if s > -INF:
             if self.best_location == AT_ANYWHERE:
                 self.best_list.add(i, j, s)

@@ -48,6 +48,7 @@ class OcResult(C.Structure):
         ("special_rows", C.c_void_p),
         ("last_row", C.c_void_p),
         ("last_col", C.c_void_p),
+        ("block_scores", C.c_void_p), ("grid_w", C.c_int), ("grid_h", C.c_int),
     ]
 
 
@@ -179,6 +180,11 @@ def stage1(seq0, seq1, recurrence=SMITH_WATERMAN, first_row_type=INIT_WITH_ZEROE
     if r.last_col:
         buf = (C.c_int32 * ((m + 1) * 2)).from_address(r.last_col)
         out["last_col"] = np.frombuffer(buf, dtype=np.int32).reshape(m + 1, 2).copy()
+    if r.block_scores:      # {(bx, by): (i, j, score)} 0-based cells, as dispatchScore(score, bx, by) receives them
+        buf = (C.c_int32 * (r.grid_w * r.grid_h * 3)).from_address(r.block_scores)
+        a = np.frombuffer(buf, dtype=np.int32).reshape(r.grid_w, r.grid_h, 3)
+        out["block_scores"] = {(bx, by): tuple(int(x) for x in a[bx, by]) for bx in range(r.grid_w) for by in range(r.grid_h)}
+        out["grid"] = (r.grid_h, r.grid_w)
     lib().oracle_free_result(C.byref(r))
     return out
 
@@ -254,6 +260,14 @@ def read_ref_work(work, log=""):
         pth = os.path.join(work, fn)
         if os.path.exists(pth):
             out[key] = open(pth, "rb").read()
+    pth = os.path.join(work, "pruning_dump.txt")         # --dump-blocks: BlocksFile.cpp:44-64 (binary despite its name)
+    if os.path.exists(pth):
+        raw = np.fromfile(pth, dtype=np.int32)
+        gh, gw = int(raw[0]), int(raw[1])
+        grid = np.full(gh * gw, -2 ** 31, dtype=np.int64)
+        grid[:len(raw) - 2] = raw[2:2 + gh * gw]      # blocks never written stay holes (the file is sparse up to the last one)
+        out["blocks_file"] = open(pth, "rb").read()
+        out["blocks"] = grid.reshape(gh, gw)
     for st in range(2, 5):
         pth = os.path.join(work, "crosspoints", "crosspoint_%02d.00" % st)
         if os.path.exists(pth):

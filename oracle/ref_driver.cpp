@@ -241,7 +241,7 @@ static long long parse_size(const char* s) {
  *   --work-dir=DIR --stage-1 --edges=XY --disk-size=N[KMG] --no-flush
  *   --no-block-pruning --block=H,W --split=COUNT --part=STEP
  *   --flush-column=URL --load-column=URL --max-alignments=N
- *   --trim=I0,I1,J0,J1 --clear-n --reverse=1|2|both --complement=1|2|both --reverse-complement=1|2|both
+ *   --dump-blocks --trim=I0,I1,J0,J1 --clear-n --reverse=1|2|both --complement=1|2|both --reverse-complement=1|2|both
  */
 int main(int argc, char** argv) {
     std::string work = "./work.tmp";
@@ -254,6 +254,7 @@ int main(int argc, char** argv) {
     int max_alignments = 1;
     std::string flush_url, load_url;
     bool gpu_stage4 = false;
+    bool dump_blocks = false;
     bool do_fork = false;
     std::vector<int> fork_weights;
     std::vector<const char*> files;
@@ -282,6 +283,7 @@ int main(int argc, char** argv) {
         else if (!strncmp(s, "--reverse=", 10)) parse_seq_flags(s + 10, reverse_seq);
         else if (!strncmp(s, "--complement=", 13)) parse_seq_flags(s + 13, complement_seq);
         else if (!strncmp(s, "--reverse-complement=", 21)) { parse_seq_flags(s + 21, complement_seq); reverse_seq[0] = complement_seq[0]; reverse_seq[1] = complement_seq[1]; }
+        else if (!strcmp(s, "--dump-blocks")) dump_blocks = true;              /* libmasa.cpp:1082: best score of every block -> <work>/pruning_dump.txt */
         else if (!strcmp(s, "--gpu-stage4")) gpu_stage4 = true;               /* product stage 4 instead of MASA-Core's */
         else if (!strcmp(s, "--fork")) do_fork = true;                       /* weights from IAligner::getForkWeights */
         else if (!strncmp(s, "--fork=", 7)) {                                /* --fork=W1,W2,... (libmasa.cpp:964-980) */
@@ -320,7 +322,7 @@ int main(int argc, char** argv) {
     job->disk_limit = disk;
     job->ram_limit = ram;
     job->block_pruning = pruning;
-    job->dump_blocks = false;
+    job->dump_blocks = dump_blocks;
     job->setWorkPath(work);
     job->stage4_maximum_partition_size = 16;
     job->stage4_strategy = STAGE_4_STRATEGY_OPTIMIZED;

@@ -319,13 +319,16 @@ int oracle_stage1(const oc_params* p, oc_result* r) {
         }
     }
 
-    free(rowbuf); free(colbuf); free(scores); free(pr.k);
+    /* block scores as AbstractBlockAligner dispatches them (dispatchScore(score, bx, by), :343-346): kept for the
+     * tests of the engine's block-score grid; column-major like the reference's score table: [bx * gh + by] */
+    r->block_scores = scores; r->grid_w = gw; r->grid_h = gh;
+    free(rowbuf); free(colbuf); free(pr.k);
 #undef K
     return 0;
 }
 
 void oracle_free_result(oc_result* r) {
-    free(r->special_row_ids); free(r->special_rows); free(r->last_row); free(r->last_col);
+    free(r->special_row_ids); free(r->special_rows); free(r->last_row); free(r->last_col); free(r->block_scores);
     memset(r, 0, sizeof(*r));
 }
 

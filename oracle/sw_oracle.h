@@ -85,6 +85,8 @@ typedef struct {
     oc_cell* special_rows;               /* n_special_rows x (n+1) cells (malloc), cell 0 = first-column cell, f=-INF */
     oc_cell* last_row;                   /* n+1 cells (malloc) if want_last_row */
     oc_cell* last_col;                   /* m+1 cells (malloc) if want_last_col */
+    oc_score* block_scores;              /* serial schedule only: best cell of block (bx, by) at [bx * grid_h + by], 0-based */
+    int grid_w, grid_h;
 } oc_result;
 
 int oracle_stage1(const oc_params* p, oc_result* r);

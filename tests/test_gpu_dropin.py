@@ -182,3 +182,24 @@ def test_full_pipeline_with_stage4_on_the_gpu(pkg, oracle, name):
     assert "GPU STAGE 4" in out["statistics"]["statistics_04.00"]
     assert hashlib.sha256(out["crosspoints_4_txt"]).hexdigest() == case["crosspoints_4"]["file_sha256"]
     assert hashlib.sha256(out["alignment_txt"]).hexdigest() == case["alignment_txt_sha256"]
+
+
+def test_dump_blocks_file_equals_the_references(pkg, oracle):
+    """--dump-blocks through MASA-Core: AlignerManager::dispatchScore(score, bx, by) -> BlocksFile (AlignerManager.cpp:
+    418-423).  With --strip-rows=512 --block-columns=700 the engine's grid is the grid of the reference's block aligner
+    run with --block=512,700: the two pruning_dump.txt files must be the same bytes (the expected file is rebuilt from
+    the oracle's block table, which tests/test_oracle_vs_reference.py pins on the reference's own file; where the
+    reference driver was prebuilt it is run as well)."""
+    import struct
+    m, n, bh, bw = 6000, 5000, 512, 700
+    seq = {"kind": "related", "m": m, "n": n, "cfg": 36}
+    s0, s1 = make_pair(pkg, seq)
+    out = _run(pkg, oracle, seq, ["--stage-1", "--no-flush", "--no-block-pruning", "--dump-blocks", "--strip-rows=%d" % bh, "--block-columns=%d" % bw])
+    o = oracle.stage1(s0, s1, block_h=bh, block_w=bw)
+    gh, gw = o["grid"]
+    want = struct.pack("<ii", gh, gw) + b"".join(struct.pack("<i", o["block_scores"][(bx, by)][2]) for by in range(gh) for bx in range(gw))
+    assert tuple(out["best"]) == tuple(o["best"])
+    assert out["blocks_file"] == want
+    if oracle.have_ref():
+        ref = oracle.run_ref(s0, s1, ["--stage-1", "--no-flush", "--no-block-pruning", "--dump-blocks", "--block=%d,%d" % (bh, bw)])
+        assert ref["blocks_file"] == out["blocks_file"]

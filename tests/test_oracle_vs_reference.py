@@ -34,3 +34,24 @@ def test_pruning_live(ref, pkg):
     assert o["blocks_pruned"] > 0
     off = ref.stage1(s0, s1, block_h=200, block_w=200, pruning=False)
     assert off["best"] == o["best"]
+
+
+@pytest.mark.parametrize("m,n,bh,bw,edges", [(3000, 2500, 512, 700, None), (2049, 1000, 256, 333, None), (1800, 2100, 256, 512, "++")])
+def test_block_scores_live(ref, pkg, m, n, bh, bw, edges):
+    """--dump-blocks: the best score of every block as MASA-Core's BlocksFile stores it (AlignerManager.cpp:418-423,
+    BlocksFile.cpp:44-64) = the oracle's block table -- which is what pins the engine's block scores on the GPU."""
+    s0, s1 = pkg.seqgen.related_pair(m, n, cfg=35)
+    args = ["--stage-1", "--no-flush", "--no-block-pruning", "--block=%d,%d" % (bh, bw), "--dump-blocks"]
+    kw = {}
+    if edges == "++":
+        args.append("--edges=++")
+        kw = dict(recurrence=ref.NEEDLEMAN_WUNSCH, first_row_type=ref.INIT_WITH_GAPS, first_col_type=ref.INIT_WITH_GAPS,
+                  best_mode=ref.BEST_LAST_CELL)
+    r = ref.run_ref(s0, s1, args)
+    o = ref.stage1(s0, s1, block_h=bh, block_w=bw, **kw)
+    gh, gw = o["grid"]
+    assert r["blocks"].shape == (gh, gw)
+    mine = np.array([[o["block_scores"][(bx, by)][2] for bx in range(gw)] for by in range(gh)])
+    if edges == "++":     # the last cell is dispatched as the score of the last block (AbstractBlockAligner.cpp:343-346 after :330-338)
+        mine[-1, -1] = o["best"][2]
+    assert np.array_equal(mine, r["blocks"])
