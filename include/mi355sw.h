@@ -286,6 +286,20 @@ int mi355sw_stage4(mi355sw_handle* h, const mi355sw_crosspoint* in, int32_t coun
                    mi355sw_crosspoint** out, int32_t* out_count, mi355sw_stage4_stats* stats);
 void mi355sw_free(void* p);
 
+/* ---- stage 5: the exact alignment of every partition between consecutive crosspoints ----------------------------
+ * Replaces the per-partition full-matrix traceback of MASA-Core's stage 5 (M/stage5/sw_stage5.cpp: sw() :83-319, the
+ * loop of stage5() :322-485).  Host code, like the reference's (no handle, no GPU): `crosspoints` = crosspoint_04.NN
+ * (partitions of at most 16 x 16 after stage 4; the reference's own limit of 8192 per side is enforced), seq0 / seq1 =
+ * the sequence data as the reference's Sequence::getData() gives it (modifiers applied).  Returns the gap events in
+ * the order the reference's traceback emits them -- gaps0[k] = DP row i of an event for sequence 0's gap list
+ * (_dot type 2, :64-80), gaps1[k] = DP column j of one for sequence 1's list (type 1); release both with mi355sw_free --
+ * and the alignment's totals.  MI355SW_ETRACEBACK: partition *failed_at has no traceback (the crosspoints are not on
+ * one optimal path). */
+typedef struct { int64_t score, matches, mismatches, gap_open, gap_extensions; } mi355sw_stage5_totals;
+int mi355sw_stage5(const char* seq0, int32_t seq0_len, const char* seq1, int32_t seq1_len, const mi355sw_crosspoint* crosspoints,
+                   int32_t count, int32_t** gaps0, int64_t* n_gaps0, int32_t** gaps1, int64_t* n_gaps1,
+                   mi355sw_stage5_totals* totals, int32_t* failed_at);
+
 /* device enumeration: X/cuda_util.cpp:191-287 (--list-gpus, GPU weights) */
 int mi355sw_device_count(void);
 int mi355sw_device_info(int32_t device, char* name, size_t name_len, int32_t* compute_units, int32_t* clock_mhz, int64_t* hbm_bytes);

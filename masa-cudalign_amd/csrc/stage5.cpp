@@ -1,0 +1,132 @@
+// Stage 5 on the host: the exact alignment of every partition between two consecutive crosspoints of crosspoint_04
+// (at most 16 x 16 after stage 4), by a full-matrix Gotoh pass and a traceback that honours the crosspoint types.
+// Replaces M/stage5/sw_stage5.cpp (sw() :83-319, the loop of stage5() :322-485) -- single-threaded CPU code in the
+// reference too; a 10 M-column alignment is ~700 k partitions of <= 256 cells, milliseconds here.
+// The caller (masa-cudalign_amd/stage56.py) turns the gap events into Alignment.cpp's gap lists.
+#include "../../include/mi355sw.h"
+
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+namespace {
+
+enum { GAP_OPEN = 3, GAP_EXT = 2, MATCH = 1, MISMATCH = -3, GAP_FIRST = GAP_OPEN + GAP_EXT, NINF = -999999999 };
+enum { TYPE_MATCH = 0, TYPE_GAP_1 = 1, TYPE_GAP_2 = 2 };
+
+struct Out {
+    std::vector<int32_t> g0, g1;     // gap events: DP row i of a gap in sequence 0's list, DP column j of one in sequence 1's
+    mi355sw_stage5_totals tot;
+};
+
+// _dot (sw_stage5.cpp:64-80): type 1 = the path moves along S0 only -> a gap character in S1 at column j; 2 = the reverse
+inline void dot(Out& o, int i, int j, int typ) {
+    if (typ == 1) o.g1.push_back(j);
+    else if (typ == 2) o.g0.push_back(i);
+}
+
+// sw() (:83-319): rows (i0, i1], columns (j0, j1]; returns 0, or -1 when the traceback finds no predecessor
+int sw(Out& o, const unsigned char* d0, const unsigned char* d1, int i0, int j0, int i1, int j1, int type_s, int type_e,
+       std::vector<int>& H, std::vector<int>& E, std::vector<int>& F) {
+    mi355sw_stage5_totals& t = o.tot;
+    if (i0 == i1) {
+        long long s = (long long) (j1 - j0) * -GAP_EXT;
+        if (type_s != TYPE_GAP_1) { t.gap_open++; s += -GAP_OPEN; }
+        for (int j = j1; j > j0; j--) { dot(o, i0, j, 2); t.gap_extensions++; }
+        t.score += s;
+        return 0;
+    }
+    if (j0 == j1) {
+        long long s = (long long) (i1 - i0) * -GAP_EXT;
+        if (type_s != TYPE_GAP_2) { t.gap_open++; s += -GAP_OPEN; }
+        for (int i = i1; i > i0; i--) { dot(o, i, j0, 1); t.gap_extensions++; }
+        t.score += s;
+        return 0;
+    }
+    const int rows = i1 - i0, cols = j1 - j0, W = cols + 1;
+    const unsigned char* a = d0 + i0;
+    const unsigned char* b = d1 + j0;
+    H.assign((size_t) (rows + 1) * W, 0);
+    E.assign((size_t) (rows + 1) * W, NINF);
+    F.assign((size_t) (rows + 1) * W, NINF);
+    for (int j = 1; j <= cols; j++) H[j] = -j * GAP_EXT - GAP_OPEN * (type_s != TYPE_GAP_1);
+    H[0] = type_s != 0 ? NINF : 0;
+    for (int i = 1; i <= rows; i++) {
+        int* hi = &H[(size_t) i * W]; const int* hp = hi - W;
+        int* ei = &E[(size_t) i * W]; const int* ep = ei - W;
+        int* fi = &F[(size_t) i * W];
+        hi[0] = -i * GAP_EXT - GAP_OPEN * (type_s != TYPE_GAP_2);
+        const unsigned char s = a[i - 1];
+        for (int j = 1; j <= cols; j++) {
+            const int ev = std::max(hp[j] - GAP_FIRST, ep[j] - GAP_EXT);
+            const int fv = std::max(hi[j - 1] - GAP_FIRST, fi[j - 1] - GAP_EXT);
+            ei[j] = ev; fi[j] = fv;
+            hi[j] = std::max(std::max(hp[j - 1] + (s == b[j - 1] ? MATCH : MISMATCH), ev), fv);
+        }
+    }
+    int i = rows, j = cols;
+    int c = type_e;                       // 0 aligned, TYPE_GAP_2, TYPE_GAP_1
+    long long total = 0;
+    while (i > 0 && j > 0) {
+        const int eh = H[(size_t) (i - 1) * W + j] - GAP_FIRST;
+        const int fh = H[(size_t) i * W + j - 1] - GAP_FIRST;
+        const int h11 = H[(size_t) (i - 1) * W + j - 1] + (a[i - 1] == b[j - 1] ? MATCH : MISMATCH);
+        const int h10 = E[(size_t) i * W + j], h01 = F[(size_t) i * W + j], h00 = H[(size_t) i * W + j];
+        int d;
+        if (c == 0) {
+            if (h00 == h11) { d = 0; c = TYPE_MATCH; }
+            else if (h00 == h10) { d = 1; c = (h10 == eh) ? TYPE_MATCH : TYPE_GAP_2; }
+            else if (h00 == h01) { d = 2; c = (h01 == fh) ? TYPE_MATCH : TYPE_GAP_1; }
+            else return -1;
+        } else if (c == TYPE_GAP_2) { d = 1; c = (h10 == eh) ? TYPE_MATCH : TYPE_GAP_2; }
+        else { d = 2; c = (h01 == fh) ? TYPE_MATCH : TYPE_GAP_1; }
+        dot(o, i0 + i, j0 + j, d);
+        if (d == 0) {
+            if (a[i - 1] == b[j - 1]) { t.matches++; total += MATCH; }
+            else { t.mismatches++; total += MISMATCH; }
+            i--; j--;
+        } else {
+            if (c == TYPE_MATCH) { t.gap_open++; total += -GAP_FIRST; }
+            else total += -GAP_EXT;
+            t.gap_extensions++;
+            if (d == 1) i--; else j--;
+        }
+    }
+    while (i > 0) { dot(o, i0 + i, j0 + j, 1); i--; t.gap_extensions++; c = TYPE_GAP_2; total += -GAP_EXT; }
+    while (j > 0) { dot(o, i0 + i, j0 + j, 2); j--; t.gap_extensions++; c = TYPE_GAP_1; total += -GAP_EXT; }
+    if (type_s == TYPE_MATCH && c != TYPE_MATCH) total -= GAP_OPEN;
+    t.score += total;
+    return 0;
+}
+
+int32_t* give(const std::vector<int32_t>& v) {
+    int32_t* p = (int32_t*) malloc(sizeof(int32_t) * (v.size() ? v.size() : 1));
+    if (p && !v.empty()) memcpy(p, v.data(), sizeof(int32_t) * v.size());
+    return p;
+}
+
+}  // namespace
+
+extern "C" int mi355sw_stage5(const char* seq0, int32_t len0, const char* seq1, int32_t len1, const mi355sw_crosspoint* cps,
+                              int32_t count, int32_t** gaps0, int64_t* n0, int32_t** gaps1, int64_t* n1,
+                              mi355sw_stage5_totals* totals, int32_t* failed_at) {
+    if (!seq0 || !seq1 || !cps || count < 1 || !gaps0 || !n0 || !gaps1 || !n1 || !totals) return MI355SW_EINVAL;
+    Out o;
+    memset(&o.tot, 0, sizeof(o.tot));
+    std::vector<int> H, E, F;
+    for (int k = 0; k + 1 < count; k++) {
+        const mi355sw_crosspoint &p = cps[k], &q = cps[k + 1];
+        if (p.i < 0 || p.j < 0 || q.i > len0 || q.j > len1 || q.i < p.i || q.j < p.j) { if (failed_at) *failed_at = k; return MI355SW_EINVAL; }
+        // W_MAX of the reference (sw_stage5.cpp:40): stage 4 must have run first
+        if (q.i != p.i && q.j != p.j && (q.i - p.i > 8192 || q.j - p.j > 8192)) { if (failed_at) *failed_at = k; return MI355SW_ETOOLARGE; }
+        if (sw(o, (const unsigned char*) seq0, (const unsigned char*) seq1, p.i, p.j, q.i, q.j, p.type, q.type, H, E, F) != 0) {
+            if (failed_at) *failed_at = k;
+            return MI355SW_ETRACEBACK;
+        }
+    }
+    *gaps0 = give(o.g0); *n0 = (int64_t) o.g0.size();
+    *gaps1 = give(o.g1); *n1 = (int64_t) o.g1.size();
+    if (!*gaps0 || !*gaps1) { free(*gaps0); free(*gaps1); return MI355SW_ENOMEM; }
+    *totals = o.tot;
+    return MI355SW_OK;
+}

@@ -100,6 +100,11 @@ class Stage4Stats(C.Structure):
     _fields_ = [("steps", C.c_int32), ("kernel_ms", C.c_double), ("dp_cells", C.c_int64), ("partitions", C.c_int64)]
 
 
+class Stage5Totals(C.Structure):
+    _fields_ = [("score", C.c_int64), ("matches", C.c_int64), ("mismatches", C.c_int64), ("gap_open", C.c_int64),
+                ("gap_extensions", C.c_int64)]
+
+
 class PortHandle(C.Structure):
     """mi355sw_port_handle: what the owner of a column port sends to the band on its left (hipIpc handle + size)."""
     _fields_ = [("ipc", C.c_ubyte * 64), ("bytes", C.c_int64), ("rows", C.c_int32), ("device", C.c_int32)]
@@ -145,7 +150,7 @@ ABI_SYMBOLS = [
     "mi355sw_stream_abort", "mi355sw_stream_end", "mi355sw_stream_strip_scores",
     "mi355sw_stream_best_hint", "mi355sw_stream_running_best",
     "mi355sw_port_create", "mi355sw_port_open", "mi355sw_port_attach", "mi355sw_port_reset", "mi355sw_port_rows_ready", "mi355sw_port_read",
-    "mi355sw_port_local_pointers", "mi355sw_port_close", "mi355sw_stage4", "mi355sw_free",
+    "mi355sw_port_local_pointers", "mi355sw_port_close", "mi355sw_stage4", "mi355sw_free", "mi355sw_stage5",
     "mi355sw_device_count", "mi355sw_device_info",
 ]
 
@@ -210,10 +215,36 @@ def load_library():
                                    C.POINTER(Stage4Stats)]
     lib.mi355sw_free.argtypes = [C.c_void_p]
     lib.mi355sw_free.restype = None
+    lib.mi355sw_stage5.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32,
+                                   C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(C.c_void_p), C.POINTER(C.c_int64),
+                                   C.POINTER(Stage5Totals), C.POINTER(C.c_int32)]
     lib.mi355sw_device_info.argtypes = [C.c_int32, C.c_char_p, C.c_size_t, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                         C.POINTER(C.c_int64)]
     _lib = lib
     return lib
+
+
+def stage5_events(data0, data1, crosspoints):
+    """mi355sw_stage5 (host code, no GPU): gap events of the exact alignment through `crosspoints` [(type, i, j, score)].
+    Returns (rows of the events for sequence 0's gap list, columns of those for sequence 1's, totals dict)."""
+    lib = load_library()
+    d0, d1 = _as_u8(data0), _as_u8(data1)
+    cp = np.ascontiguousarray(crosspoints, dtype=np.int32).reshape(-1, 4)
+    g0, g1, n0, n1 = C.c_void_p(), C.c_void_p(), C.c_int64(), C.c_int64()
+    tot, bad = Stage5Totals(), C.c_int32(-1)
+    rc = lib.mi355sw_stage5(d0.ctypes.data, len(d0), d1.ctypes.data, len(d1), cp.ctypes.data, len(cp), C.byref(g0), C.byref(n0),
+                            C.byref(g1), C.byref(n1), C.byref(tot), C.byref(bad))
+    if rc != 0:
+        raise AlignerError("stage5: %s at partition %d (crosspoints %s -> %s)" % (
+            ERRORS.get(rc, rc), bad.value, tuple(cp[bad.value]) if 0 <= bad.value < len(cp) else None,
+            tuple(cp[bad.value + 1]) if 0 <= bad.value + 1 < len(cp) else None))
+    try:
+        a0 = np.frombuffer((C.c_int32 * max(n0.value, 1)).from_address(g0.value), dtype=np.int32)[:n0.value].copy()
+        a1 = np.frombuffer((C.c_int32 * max(n1.value, 1)).from_address(g1.value), dtype=np.int32)[:n1.value].copy()
+    finally:
+        lib.mi355sw_free(g0)
+        lib.mi355sw_free(g1)
+    return a0, a1, {k: int(getattr(tot, k)) for k, _ in Stage5Totals._fields_}
 
 
 def _as_u8(seq):

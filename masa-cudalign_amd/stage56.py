@@ -3,7 +3,8 @@
 Restates MASA-Core's M/stage5/sw_stage5.cpp (sw() :83-319: exact alignment of every partition of at most 16 x 16 with a
 full-matrix traceback that honours the crosspoint types; stage5() :322-485), M/common/biology/Alignment.cpp (gap lists:
 addGap :207-218, finalize :120-130) and the default text output of M/stage6/sw_stage6.cpp (printText :60-262).
-Pure host code (the reference's is single-threaded CPU code too): ~0.3 % of the pipeline's time on top of the engine.
+Host code like the reference's (single-threaded CPU code there): the per-partition matrices of stage 5 run in the C
+library (csrc/stage5.cpp), the gap lists and the text are assembled here.
 
     crosspoints: [(type, i, j, score), ...] of crosspoint_04 (type 0 aligned, 1 gap in S0 -- the path moves along S1 --,
                  2 gap in S1), i/j = DP coordinates
@@ -37,127 +38,39 @@ class Alignment:
             g.sort(key=lambda x: x[0])
 
 
-def _dot(al, seq0, seq1, i, j, typ):
-    """sw_stage5.cpp:64-80"""
-    if typ == 1:
-        al.add_gap(1, seq1.absolute_pos(j + (0 if seq1.modifiers.reverse else 1)))
-    elif typ == 2:
-        al.add_gap(0, seq0.absolute_pos(i + (0 if seq0.modifiers.reverse else 1)))
-
-
-def _sw(al, seq0, seq1, d0, d1, i0, j0, i1, j1, type_s, type_e, tot):
-    """sw_stage5.cpp:83-319; d0/d1 = the data arrays (Sequence::getData()), rows (i0, i1], columns (j0, j1]"""
-    if i0 == i1:
-        s = (j1 - j0) * -GAP_EXT
-        if type_s != TYPE_GAP_1:
-            tot["gapOpen"] += 1
-            s += -GAP_OPEN
-        for j in range(j1, j0, -1):
-            _dot(al, seq0, seq1, i0, j, 2)
-            tot["gapExtensions"] += 1
-        tot["score"] += s
-        return s
-    if j0 == j1:
-        s = (i1 - i0) * -GAP_EXT
-        if type_s != TYPE_GAP_2:
-            tot["gapOpen"] += 1
-            s += -GAP_OPEN
-        for i in range(i1, i0, -1):
-            _dot(al, seq0, seq1, i, j0, 1)
-            tot["gapExtensions"] += 1
-        tot["score"] += s
-        return s
-    rows, cols = i1 - i0, j1 - j0
-    # (with an aligned end point the reference computes one more row and column and steps back over them before the
-    #  traceback starts, :104-108 / :186-190: the traceback never looks at them)
-    a, b = d0[i0:i1], d1[j0:j1]
-    h = [[0] * (cols + 1) for _ in range(rows + 1)]
-    e = [[-INF] * (cols + 1) for _ in range(rows + 1)]
-    f = [[-INF] * (cols + 1) for _ in range(rows + 1)]
-    for j in range(1, cols + 1):
-        h[0][j] = -j * GAP_EXT - GAP_OPEN * (type_s != TYPE_GAP_1)
-    h[0][0] = -INF if type_s != 0 else 0
-    for i in range(1, rows + 1):
-        hi, hp, ei, ep, fi = h[i], h[i - 1], e[i], e[i - 1], f[i]
-        hi[0] = -i * GAP_EXT - GAP_OPEN * (type_s != TYPE_GAP_2)
-        s = a[i - 1]
-        for j in range(1, cols + 1):
-            ev = max(hp[j] - GAP_FIRST, ep[j] - GAP_EXT)
-            fv = max(hi[j - 1] - GAP_FIRST, fi[j - 1] - GAP_EXT)
-            ei[j], fi[j] = ev, fv
-            hi[j] = max(hp[j - 1] + (MATCH if s == b[j - 1] else MISMATCH), ev, fv)
-    i, j = rows, cols
-    c = {0: TYPE_MATCH, TYPE_GAP_2: TYPE_GAP_2, TYPE_GAP_1: TYPE_GAP_1}[type_e]
-    total = 0
-    while i > 0 and j > 0:
-        _eh = h[i - 1][j] - GAP_FIRST
-        _fh = h[i][j - 1] - GAP_FIRST
-        _h11 = h[i - 1][j - 1] + (MATCH if a[i - 1] == b[j - 1] else MISMATCH)
-        _h10, _h01, _h00 = e[i][j], f[i][j], h[i][j]
-        if c == 0:
-            if _h00 == _h11:
-                d, c = 0, TYPE_MATCH
-            elif _h00 == _h10:
-                d, c = 1, (TYPE_MATCH if _h10 == _eh else TYPE_GAP_2)
-            elif _h00 == _h01:
-                d, c = 2, (TYPE_MATCH if _h01 == _fh else TYPE_GAP_1)
-            else:
-                raise RuntimeError("stage5: traceback lost at (%d,%d)" % (i0 + i, j0 + j))
-        elif c == TYPE_GAP_2:
-            d, c = 1, (TYPE_MATCH if _h10 == _eh else TYPE_GAP_2)
-        else:
-            d, c = 2, (TYPE_MATCH if _h01 == _fh else TYPE_GAP_1)
-        _dot(al, seq0, seq1, i0 + i, j0 + j, d)
-        if d == 0:
-            if a[i - 1] == b[j - 1]:
-                tot["matches"] += 1
-                total += MATCH
-            else:
-                tot["mismatches"] += 1
-                total += MISMATCH
-            i -= 1
-            j -= 1
-        else:
-            if c == TYPE_MATCH:
-                tot["gapOpen"] += 1
-                total += -GAP_FIRST
-            else:
-                total += -GAP_EXT
-            tot["gapExtensions"] += 1
-            if d == 1:
-                i -= 1
-            else:
-                j -= 1
-    while i > 0:
-        _dot(al, seq0, seq1, i0 + i, j0 + j, 1)
-        i -= 1
-        tot["gapExtensions"] += 1
-        c = TYPE_GAP_2
-        total += -GAP_EXT
-    while j > 0:
-        _dot(al, seq0, seq1, i0 + i, j0 + j, 2)
-        j -= 1
-        tot["gapExtensions"] += 1
-        c = TYPE_GAP_1
-        total += -GAP_EXT
-    if type_s == TYPE_MATCH and c != TYPE_MATCH:
-        total -= GAP_OPEN
-    tot["score"] += total
-    return total
+def _gap_list(positions):
+    """Alignment::addGap (:207-218) over a run of events -- an event at the position of the entry before it extends that
+    entry -- then Alignment::finalize's sort by position (:120-130; stable, as list.sort was)"""
+    if len(positions) == 0:
+        return []
+    p = np.asarray(positions, dtype=np.int64)
+    starts = np.flatnonzero(np.concatenate(([True], p[1:] != p[:-1])))
+    lens = np.diff(np.concatenate((starts, [len(p)])))
+    pos = p[starts]
+    order = np.argsort(pos, kind="stable")
+    return [[int(a), int(b)] for a, b in zip(pos[order], lens[order])]
 
 
 def stage5(seq0, seq1, crosspoints):
-    """stage5(), sw_stage5.cpp:322-485: the Alignment of the path through `crosspoints`"""
+    """stage5(), sw_stage5.cpp:322-485: the Alignment of the path through `crosspoints`.  The per-partition matrices and
+    tracebacks (sw(), :83-319) run in the library (mi355sw_stage5, csrc/stage5.cpp: host code like the reference's, a
+    10 M-column alignment takes well under a second); here the gap events become Alignment.cpp's gap lists."""
+    from .engine import stage5_events, AlignerError
     al = Alignment()
-    tot = dict(score=0, matches=0, mismatches=0, gapOpen=0, gapExtensions=0)
-    d0, d1 = seq0.data(), seq1.data()
-    if max((max(abs(q[1] - p[1]), abs(q[2] - p[2])) for p, q in zip(crosspoints, crosspoints[1:])
-            if q[1] != p[1] and q[2] != p[2]), default=0) > 8192:
-        raise ValueError("stage5: a partition is larger than the reference's W_MAX; run stage 4 first")
-    m0 = crosspoints[0]
-    for m1 in crosspoints[1:]:
-        _sw(al, seq0, seq1, d0, d1, m0[1], m0[2], m1[1], m1[2], m0[0], m1[0], tot)
-        m0 = m1
+    try:
+        rows0, cols1, tot = stage5_events(seq0.data(), seq1.data(), crosspoints)
+    except AlignerError as e:
+        if "ETOOLARGE" in str(e):
+            raise ValueError("stage5: a partition is larger than the reference's W_MAX; run stage 4 first")
+        raise RuntimeError(str(e))
+    # _dot (:64-80): DP row / column -> absolute position in the original sequence (Sequence::getAbsolutePos)
+    p0 = rows0.astype(np.int64) + (0 if seq0.modifiers.reverse else 1)
+    p1 = cols1.astype(np.int64) + (0 if seq1.modifiers.reverse else 1)
+    if seq0.modifiers.reverse:
+        p0 = seq0.original_size + 1 - p0
+    if seq1.modifiers.reverse:
+        p1 = seq1.original_size + 1 - p1
+    al.gaps = (_gap_list(p0), _gap_list(p1))
     start, end = crosspoints[0], crosspoints[-1]
     if len(crosspoints) != 1:
         al.start = [seq0.absolute_pos(start[1] + 1), seq1.absolute_pos(start[2] + 1)]
@@ -166,8 +79,7 @@ def stage5(seq0, seq1, crosspoints):
     if correct != tot["score"]:
         raise RuntimeError("stage5: Wrong Alignment Score: %d != %d" % (tot["score"], correct))
     al.raw_score, al.matches, al.mismatches = tot["score"], tot["matches"], tot["mismatches"]
-    al.gap_open, al.gap_extensions = tot["gapOpen"], tot["gapExtensions"]
-    al.finalize()
+    al.gap_open, al.gap_extensions = tot["gap_open"], tot["gap_extensions"]
     return al
 
 
