@@ -44,15 +44,16 @@ PMC_INDEX = os.path.join(ROOT, "profiles", "pmc_index.json")
 
 
 def kernel_build_id():
-    """sha256 over everything the device code is built from"""
-    import hashlib
-    h = hashlib.sha256()
-    src = os.path.join(graft.PKG_DIR, "csrc")
-    for fn in sorted(os.listdir(src)):
-        if fn.endswith((".hip", ".inc", ".h", ".py", ".sh")) or fn == "Makefile":
-            h.update(fn.encode())
-            h.update(open(os.path.join(src, fn), "rb").read())
-    return h.hexdigest()[:16]
+    """identity of the device code of the LOADED library (mi355sw_build_id: the hash of csrc/ compiled into it).  PMC
+    figures are quoted only when library id = id of the sources in the tree = key of profiles/pmc_index.json."""
+    from masa_cudalign_amd import engine
+    return engine.library_build_id()
+
+
+def build_identity():
+    from masa_cudalign_amd import engine
+    lib, src = engine.library_build_id(), engine.source_build_id()
+    return {"library": lib, "sources": src, "stale_library": lib != src}
 
 
 def pmc_lookup(kernel, m, n, strip_rows):
@@ -60,7 +61,10 @@ def pmc_lookup(kernel, m, n, strip_rows):
         idx = json.load(open(PMC_INDEX))
     except (OSError, ValueError):
         return None
-    return idx.get(kernel_build_id(), {}).get("%s:%dx%d:%d" % (kernel, m, n, strip_rows))
+    ident = build_identity()
+    if ident["stale_library"]:          # the .so was not built from the sources next to it: nothing measured applies
+        return None
+    return idx.get(ident["library"], {}).get("%s:%dx%d:%d" % (kernel, m, n, strip_rows))
 
 
 def cpu_baseline(pkg, seconds_budget=20.0):
@@ -272,7 +276,7 @@ def main():
                         % (args.tall, args.size * args.tall, world, n, world, n // world, comm)),
                        "m": m, "n": n, "bands": world, "strip_rows": st["strip_rows"], "waves_per_gpu": st["waves"],
                        "kernel": {2: "pk16", 1: "int32-profile", 0: "int32-generic"}[st["profile_kernel"]],
-                       "comm": comm if world > 1 else "none", "comm_note": comm_note, "kernel_build_id": kernel_build_id()},
+                       "comm": comm if world > 1 else "none", "comm_note": comm_note, "kernel_build_id": kernel_build_id(), "build_identity": build_identity()},
             "best": {"i": best[0] + 1, "j": best[1] + 1, "score": best[2]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,

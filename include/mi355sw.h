@@ -143,6 +143,9 @@ int mi355sw_create(const mi355sw_config* config, mi355sw_handle** out);
 void mi355sw_destroy(mi355sw_handle* h);
 const char* mi355sw_last_error(mi355sw_handle* h);
 int mi355sw_abi_version(void);
+/* identity of the device code this library was built from: sha256 (16 hex digits) over the kernel sources and their
+ * build recipe (csrc/build_id.py).  Measurements (rocprof counters) are keyed by it. */
+const char* mi355sw_build_id(void);
 
 /* IAligner::getCapabilities (IAligner.hpp:159; X/CUDAligner.cpp:87-111) */
 int mi355sw_get_capabilities(mi355sw_handle* h, mi355sw_capabilities* out);

@@ -19,6 +19,9 @@ $LLVM/llvm-objdump -d "$tmp/dev.o" > "$tmp/dev.objdump"
 python3 "$here/align8.py" "$tmp/dev.s" "$tmp/dev.objdump" "$tmp/dev.al.s"
 $LLVM/clang -target amdgcn-amd-amdhsa -mcpu=$ARCH -c -x assembler "$tmp/dev.al.s" -o "$tmp/dev.al.o"
 $LLVM/lld -flavor gnu -m elf64_amdgpu --no-undefined -shared -o "$tmp/dev.co" "$tmp/dev.al.o"
+# what the assembled kernels really occupy (.vgpr_count / .agpr_count / .private_segment_fixed_size per kernel): kept next
+# to the object, tools/kernel_resources.py turns the notes into the table under profiles/
+$LLVM/llvm-readelf --notes "$tmp/dev.co" > "$(dirname "$out")/$(basename "$out" .o).notes.txt"
 $LLVM/clang-offload-bundler -type=o -bundle-align=4096 -targets=host-x86_64-unknown-linux-gnu,hipv4-amdgcn-amd-amdhsa--$ARCH \
     -input=/dev/null -input="$tmp/dev.co" -output="$tmp/dev.hipfb"
 hipcc --offload-arch=$ARCH "$@" --cuda-host-only -Xclang -fcuda-include-gpubinary -Xclang "$tmp/dev.hipfb" -c "$src" -o "$out"

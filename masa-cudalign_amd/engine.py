@@ -140,7 +140,7 @@ class ManagerTable(C.Structure):
 
 # every symbol include/mi355sw.h declares (tests check the .so exports all of them)
 ABI_SYMBOLS = [
-    "mi355sw_create", "mi355sw_destroy", "mi355sw_last_error", "mi355sw_abi_version",
+    "mi355sw_create", "mi355sw_destroy", "mi355sw_last_error", "mi355sw_abi_version", "mi355sw_build_id",
     "mi355sw_get_capabilities", "mi355sw_get_score_parameters",
     "mi355sw_set_sequences", "mi355sw_unset_sequences", "mi355sw_align_partition",
     "mi355sw_process_block", "mi355sw_match_last_column", "mi355sw_progress",
@@ -160,11 +160,27 @@ _lib = None
 def build_library(force=False):
     """Compile csrc/ for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
     src = os.path.join(HERE, "csrc")
-    deps = [os.path.join(src, f) for f in ("runtime.cpp", "sw_kernel.hip", "sw_kernel_pk16.inc", "sw_kernel_pk16_a.hip", "sw_kernel_pk16_b.hip", "sw_kernel_pk16_c.hip", "sw_kernel_pk16_d.hip", "sw_kernel_pk16_e.hip", "sw_kernel_pk16_f.hip", "sw_kernel.h")] + [INCLUDE_PATH]
+    deps = [os.path.join(src, f) for f in sorted(os.listdir(src))
+            if f.endswith((".cpp", ".hip", ".inc", ".h", ".py", ".sh")) or f == "Makefile"] + [INCLUDE_PATH]
     if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
         return LIB_PATH
     subprocess.check_call(["make", "-C", src], stdout=subprocess.DEVNULL)
     return LIB_PATH
+
+
+def library_build_id():
+    """identity of the device code the LOADED library was built from (mi355sw_build_id)"""
+    return load_library().mi355sw_build_id().decode()
+
+
+def source_build_id():
+    """the same hash over the sources in the tree now (csrc/build_id.py); differs from library_build_id() when the
+    library is stale"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("mi355sw_build_id", os.path.join(HERE, "csrc", "build_id.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.kernel_build_id()
 
 
 def load_library():
@@ -180,6 +196,7 @@ def load_library():
     lib.mi355sw_destroy.restype = None
     lib.mi355sw_last_error.argtypes = [H]
     lib.mi355sw_last_error.restype = C.c_char_p
+    lib.mi355sw_build_id.restype = C.c_char_p
     lib.mi355sw_get_capabilities.argtypes = [H, C.POINTER(Capabilities)]
     lib.mi355sw_get_score_parameters.argtypes = [H, C.POINTER(ScoreParams)]
     lib.mi355sw_set_sequences.argtypes = [H, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]

@@ -63,5 +63,61 @@ def run(case_name):
     return 0 if res["ok"] else 1
 
 
+def run_at_size(m, n):
+    """A size no fixture covers (no CPU oracle can produce one): the NATIVE stages 1-6 against the DROP-IN run of the
+    same pair -- MASA-Core's own stages 2-6 compiled from the reference, on the same engine (oracle/_ref/masa_mi355) --
+    with block pruning and special rows on disk in both.  crosspoint_02/03/04 and alignment.00.txt must be the same
+    bytes, and the alignment must re-score to the stage-1 best."""
+    import shutil
+    import subprocess
+    import time
+    import __graft_entry__ as graft
+    pkg = graft.load_package()
+    from masa_cudalign_amd import fasta, pipeline
+    from oracle.binding import _write_fasta, read_ref_work
+    binary = os.path.join(graft.ROOT, "oracle", "_ref", "masa_mi355")
+    s0, s1 = pkg.seqgen.related_pair(m, n, cfg=61)
+    tmp = tempfile.mkdtemp(prefix="mi355_native_size_")
+    try:
+        disk = "2G"
+        f0, f1 = os.path.join(tmp, "s0.fasta"), os.path.join(tmp, "s1.fasta")
+        _write_fasta(f0, s0, "s0")
+        _write_fasta(f1, s1, "s1")
+        t0 = time.time()
+        p = subprocess.run([binary, "--work-dir=" + os.path.join(tmp, "dropin"), "--disk-size=" + disk, "--strip-rows=1024", "--gpu-stage4", f0, f1],
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900, cwd=tmp)
+        t_dropin = time.time() - t0
+        if p.returncode != 0:
+            print(p.stdout.decode(errors="replace")[-3000:])
+            return 1
+        ref = read_ref_work(os.path.join(tmp, "dropin"))
+        q0, q1 = fasta.parse(open(f0, "rb").read()), fasta.parse(open(f1, "rb").read())
+        work = os.path.join(tmp, "native")
+        al = pkg.MI355Aligner(device=0, rows_per_lane=16)
+        try:
+            t0 = time.time()
+            out = pipeline.align(al, q0, q1, work, sra_limit=2 << 30, block_pruning=True)
+            t_native = time.time() - t0
+        finally:
+            al.close()
+        rd = lambda st: open(os.path.join(work, "crosspoints", "crosspoint_%02d.00" % st), "rb").read()
+        checks = {"best": tuple(out["best"]) == tuple(ref["best"]),
+                  "alignment_score": out["alignment"].raw_score == out["best"][2],
+                  "pruned": out["stage1"]["pruned_cells"] > 0.2 * m * n,
+                  "special_rows": len(out["stage1"]["special_rows"]) >= 16}
+        for st in (2, 3, 4):
+            checks["crosspoints_%d" % st] = rd(st) == ref["crosspoints_%d_txt" % st]
+        checks["alignment_txt"] = hashlib.sha256(out["text"]).hexdigest() == hashlib.sha256(ref["alignment_txt"]).hexdigest()
+        res = {"case": "at_size_%dx%d" % (m, n), "checks": checks, "ok": all(checks.values()), "best": list(out["best"]),
+               "crosspoints": out["crosspoints"], "seconds": out["seconds"], "native_seconds": t_native, "dropin_seconds": t_dropin,
+               "alignment_txt_sha256": hashlib.sha256(out["text"]).hexdigest(), "pruned_fraction": out["stage1"]["pruned_cells"] / float(m) / n}
+        print(json.dumps(res), flush=True)
+        return 0 if res["ok"] else 1
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 if __name__ == "__main__":
+    if sys.argv[1] == "at_size":
+        sys.exit(run_at_size(int(sys.argv[2]), int(sys.argv[3])))
     sys.exit(run(sys.argv[1]))

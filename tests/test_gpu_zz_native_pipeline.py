@@ -21,9 +21,9 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def _case(name, limit_s=180):
+def _case(name, limit_s=180, extra=()):
     try:
-        p = subprocess.run([sys.executable, os.path.join(HERE, "native_pipeline_cases.py"), name], stdout=subprocess.PIPE,
+        p = subprocess.run([sys.executable, os.path.join(HERE, "native_pipeline_cases.py"), name] + list(extra), stdout=subprocess.PIPE,
                            stderr=subprocess.STDOUT, timeout=limit_s)
         rc, log = p.returncode, p.stdout.decode(errors="replace")
     except subprocess.TimeoutExpired as e:
@@ -54,3 +54,13 @@ def test_native_pipeline_with_pruning_biting():
     traceback on top of them recovers the reference's crosspoints and text"""
     res = _case("pruned_60000x50000", limit_s=400)
     assert res["checks"]["pruned"] and res["checks"]["alignment_txt"]
+
+
+def test_native_pipeline_equals_the_dropin_at_4M():
+    """4 000 000 x 4 000 000 related pair, pruning biting, special rows on disk: native stages 1-6 = MASA-Core's own
+    stages on the same engine (crosspoint files and alignment.00.txt byte for byte), alignment re-scores to the best"""
+    if not os.path.exists(os.path.join(os.path.dirname(HERE), "oracle", "_ref", "masa_mi355")):
+        pytest.skip("oracle/_ref/masa_mi355 not prebuilt (needs /root/reference at build time)")
+    res = _case("at_size", limit_s=900, extra=["4000000", "4000000"])
+    assert res["checks"]["alignment_txt"] and res["checks"]["crosspoints_4"]
+    print("native %.1f s (stages %s), drop-in %.1f s" % (res["native_seconds"], res["seconds"], res["dropin_seconds"]))
