@@ -126,8 +126,13 @@ def main():
     ap.add_argument("--rows-per-lane", type=int, default=int(os.environ.get("MI355SW_R", "0")))
     ap.add_argument("--waves", type=int, default=int(os.environ.get("MI355SW_WAVES", "0")))
     ap.add_argument("--tall", type=int, default=4, help="N > 1: rows per GPU = tall * size (weak scaling)")
+    ap.add_argument("--related", action="store_true",
+                    help="a RELATED synthetic pair (2 %% substitutions, indels, one inversion) with block pruning on in every "
+                         "band against the chain-wide best score: GCUPS in the reference's m*n convention plus the pruned fraction")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-target-shape", action="store_true", help="N = 1: skip the 228 M-row north-star-height step")
+    ap.add_argument("--no-single-reference", action="store_true",
+                    help="N > 1: skip rank 0's untimed run of ONE GPU's share of the cells (tall*size x size) alone")
     args = ap.parse_args()
 
     import torch
@@ -172,7 +177,7 @@ def main():
 
     n = args.size
     m = args.size * (1 if world == 1 else args.tall * world)
-    s0, s1 = pkg.seqgen.unrelated_pair(m, n, cfg=2)
+    s0, s1 = (pkg.seqgen.related_pair if args.related else pkg.seqgen.unrelated_pair)(m, n, cfg=2)
     waves = args.waves
     if rehearse and waves == 0:
         waves = 1024 // world // 2        # all ranks' strip kernels must be resident on the one GPU together
@@ -199,10 +204,19 @@ def main():
         def all_gather(self, out, t):
             dist.all_gather(out, t)
 
+        def new_group(self, ranks, backend="gloo"):
+            return dist.new_group(ranks, backend=backend)
+
+        def all_reduce(self, t, op=None, group=None):
+            dist.all_reduce(t, op=op, group=group)
+
+        ReduceOp = dist.ReduceOp
+
     # block pruning is left off: C2 is an unrelated pair, on which the reference's (default-on) pruning
     # prunes nothing either, and the engine's kernel without the skip path is the faster one
+    # (--related: pruning on, every band against the best of the whole chain -- bands.py / include/mi355sw.h share_best)
     runner = BandRunner(al, dist=_Dist() if world > 1 else None, rank=rank, world=world, device=None,
-                        segment_rows=1 << 15, transport=comm)
+                        segment_rows=1 << 15, transport=comm, prune_blocks=args.related)
     if world > 1:
         runner.reduce_best = lambda b, _r=runner: _reduce_cpu(dist, b, world, coll_device)
     comm_note = None
@@ -227,8 +241,24 @@ def main():
             runner.transport = "host"
             al.portClose()
 
+    # N > 1: what ONE GPU does with the same number of cells as its share of the chain -- (tall*size) x size, one band,
+    # no neighbour -- so that the scaling figure compares like with like (the N = 1 line of this bench is C2, a
+    # 2-round shape that is ~10 % slower per cell than a tall one).  Rank 0, untimed, before the chain.
+    single_ref = None
+    if world > 1 and not args.no_single_reference:
+        if rank == 0:
+            mm = args.size * args.tall
+            t0s = time.time()
+            b1 = BandRunner(al).run(mm, 0, n)
+            dts = time.time() - t0s
+            st1 = al.getStatistics()
+            single_ref = {"workload": "%dx%d on rank 0 alone (one GPU's share of the chain's cells)" % (mm, n),
+                          "gcups": float(mm) * n / dts / 1e9, "seconds": dts, "kernel_ms": st1["kernel_ms"],
+                          "strip_rows": st1["strip_rows"], "best": {"i": b1[0] + 1, "j": b1[1] + 1, "score": b1[2]}}
+        dist.barrier()
+
     def one_step():
-        best = runner.run(m, j0, j1)
+        best = runner.run(m, j0, j1, n_total=n)
         if world > 1:
             best = runner.reduce_best(best)
         return best, al.getStatistics()
@@ -244,10 +274,12 @@ def main():
         best, _st = one_step()
     fence()
     t0 = time.time()
-    kernel_ms = []
+    kernel_ms, wait_ms, pruned = [], [], []
     for _ in range(args.steps):
         best, st = one_step()
         kernel_ms.append(st["kernel_ms"])
+        wait_ms.append(st.get("wait_ms", 0.0))
+        pruned.append(st["pruned_cells"])
     fence()
     dt = time.time() - t0
     if world > 1:
@@ -255,6 +287,17 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    ranks = None
+    if world > 1:
+        # who ran what where: one record per rank, gathered over the gloo side group
+        prop = torch.cuda.get_device_properties(local_rank)
+        mine = {"rank": rank, "device": local_rank, "name": prop.name,
+                "pci_bus_id": getattr(prop, "pci_bus_id", None), "pci_device_id": getattr(prop, "pci_device_id", None),
+                "band_columns": [j0, j1], "kernel_ms": sum(kernel_ms) / len(kernel_ms),
+                "wait_for_left_neighbour_ms": sum(wait_ms) / len(wait_ms),      # per wavefront, in claim_strip_common
+                "pruned_cells": sum(pruned) / len(pruned), "restarts": runner.restarts, "p2p_error": runner.p2p_error}
+        ranks = [None] * world
+        dist.all_gather_object(ranks, mine, group=p2p_group)
     if rank == 0:
         cells = float(m) * float(n)
         gcups = cells * args.steps / dt / 1e9
@@ -270,13 +313,23 @@ def main():
             "ms_per_step": dt * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "i16x2 (packed, exact; int32 fallback)" if st["profile_kernel"] == 2 else "int32",
             "data": "synthetic",
-            "config": {"workload": ("C2: %dx%d unrelated random ACGT, local SW, score-only" % (m, n)) if world == 1 else
-                       ("weak scaling, %d x C2's cells per GPU: (%d*%d)x%d unrelated random ACGT, local SW, score-only; "
+            "config": {"workload": (("C2: %dx%d unrelated random ACGT, local SW, score-only" % (m, n)) if not args.related else
+                                    ("%dx%d RELATED synthetic pair, local SW, score-only, block pruning on" % (m, n))) if world == 1 else
+                       ("weak scaling, %d x C2's cells per GPU: (%d*%d)x%d %s, local SW, score-only; "
                         "%d column bands of %d columns, boundary column GPU to GPU (%s)"
-                        % (args.tall, args.size * args.tall, world, n, world, n // world, comm)),
+                        % (args.tall, args.size * args.tall, world, n,
+                           "RELATED synthetic pair, block pruning on against the chain-wide best" if args.related else "unrelated random ACGT",
+                           world, n // world, comm)),
                        "m": m, "n": n, "bands": world, "strip_rows": st["strip_rows"], "waves_per_gpu": st["waves"],
                        "kernel": {2: "pk16", 1: "int32-profile", 0: "int32-generic"}[st["profile_kernel"]],
-                       "comm": comm if world > 1 else "none", "comm_note": comm_note, "kernel_build_id": kernel_build_id(), "build_identity": build_identity()},
+                       "comm": comm if world > 1 else "none", "comm_note": comm_note,
+                       # does the boundary column cross a GPU-to-GPU link?  Only with column ports between different
+                       # devices; the host transport (pinned columns + gloo over loopback) and a rehearsal do not
+                       "xgmi": bool(world > 1 and comm == "p2p" and not rehearse),
+                       "collectives": ({"backend": dist.get_backend(), "world": dist.get_world_size()} if world > 1 else None),
+                       "ranks": ranks, "same_shape_single_gpu": single_ref,
+                       "related_pair": bool(args.related),
+                       "pruned_fraction": ((sum(r["pruned_cells"] for r in ranks) if ranks else sum(pruned) / len(pruned)) / (float(m) * n)), "kernel_build_id": kernel_build_id(), "build_identity": build_identity()},
             "best": {"i": best[0] + 1, "j": best[1] + 1, "score": best[2]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,

@@ -136,6 +136,9 @@ typedef struct {
     int32_t profile_kernel;     /* 1 = 4-bit profile scoring, 0 = generic byte compare, 2 = packed 16-bit */
     int64_t algorithmic_bytes;  /* 17*n*ceil(m/S) + m + 8(n+1)*rows_flushed           */
     int64_t pruned_cells;       /* cells of skipped slabs (block pruning)                        */
+    double wait_ms;             /* time the strip wavefronts spent waiting for first-column rows that somebody else
+                                   delivers (the host, or the previous band's GPU through the column port), average
+                                   per wavefront: what a band of a chain loses to its left neighbour              */
 } mi355sw_stats;
 
 /* ---- life cycle: IAligner::initialize/finalize (IAligner.hpp:186,226; X/CUDAligner.cpp:137-174) ---- */

@@ -73,6 +73,8 @@ struct KernelArgs {
     const int* chain_up_in;      // next band's port +128 (peer-mapped): what the bands on the right know (remote load)
     const int* host_best_hint;   // pinned host word: a lower bound from outside (mi355sw_stream_best_hint), or nullptr
     int* host_best_report;       // pinned host word: the running best as of the last completed strip, or nullptr
+    unsigned long long* wait_acc; // 10 ns ticks the wavefronts spent in claim_strip_common waiting for first-column rows
+                                 // that somebody else delivers (host or neighbour GPU), summed over the wavefronts; or nullptr
     const int* gbest_in;         // where the strips READ the running best from: gbest itself, or a word that stays at -INF
                                  // when every strip record must be that strip's own exact best (block scores) instead
                                  // of "nothing below what is already known elsewhere"
@@ -145,6 +147,7 @@ static __device__ __attribute__((noinline, unused)) int claim_strip_common(const
             atomicExch(a->error_flag, 2);
             __hip_atomic_store(a->abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+        if (lane == 0 && a->wait_acc != nullptr) atomicAdd(a->wait_acc, (unsigned long long) (__builtin_amdgcn_s_memrealtime() - t0));
         __builtin_amdgcn_wave_barrier();
     }
     return s;

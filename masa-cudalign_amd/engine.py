@@ -79,7 +79,7 @@ class Stats(C.Structure):
     _fields_ = [("cells", C.c_int64), ("processed_cells", C.c_int64), ("kernel_ms", C.c_double),
                 ("total_ms", C.c_double), ("kernel_launches", C.c_int32), ("strips", C.c_int32),
                 ("strip_rows", C.c_int32), ("waves", C.c_int32), ("profile_kernel", C.c_int32),
-                ("algorithmic_bytes", C.c_int64), ("pruned_cells", C.c_int64)]
+                ("algorithmic_bytes", C.c_int64), ("pruned_cells", C.c_int64), ("wait_ms", C.c_double)]
 
 
 class StreamParams(C.Structure):
