@@ -189,8 +189,11 @@ static __device__ __attribute__((noinline, unused)) void complete_strip_common(c
         if (spins >= spin_limit) atomicExch(a->error_flag, 3);
         relay_running_best(a);
         const int err = __hip_atomic_load(a->error_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (err != 0 && a->host_error != nullptr)
-            __hip_atomic_store(a->host_error, err, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (err != 0 && a->host_error != nullptr) {
+            // low byte: the code; above it, for an overflow report of the packed kernel, its causes (error_flag[1])
+            const int why = __hip_atomic_load(a->error_flag + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(a->host_error, err | (why << 8), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
         if (a->peer_ready != nullptr && err == 0 &&
             __hip_atomic_load(a->abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0 &&
             (a->host_abort == nullptr || __hip_atomic_load(a->host_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0)) {
@@ -211,6 +214,7 @@ static __device__ __attribute__((noinline, unused)) void complete_strip_common(c
 // `dargs` = device copy of the argument block (the launcher uploads `a` into it on `stream`)
 hipError_t launch_strip_kernel(const KernelArgs& a, KernelArgs* dargs, int rows_per_lane, int grid, hipStream_t stream,
                                bool sw, bool profile, bool track);
+int strip_kernel_waves_per_simd();   // int32 family: wavefronts of one launch that share a SIMD (2; the packed kernels: 1)
 // packed 16-bit SW kernel (sw_kernel_pk16.inc, instantiated by sw_kernel_pk16_{a,b,c}.hip): strip height = 128*rows_per_half
 hipError_t launch_strip_kernel_pk16(const KernelArgs& a, KernelArgs* dargs, int rows_per_half, int grid, hipStream_t stream, bool track, bool sw);
 // stage 4 (stage4.hip): Myers-Miller refinement of a crosspoint list, batched on the GPU

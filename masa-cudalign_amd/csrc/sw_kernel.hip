@@ -344,15 +344,34 @@ __device__ __attribute__((noinline)) void process_strip(const KernelArgs* ap, co
     }
 }
 
+// TWO wavefronts per SIMD for this family (the packed kernels keep one): its inner loop is v_max_i32 / v_add_u32 /
+// v_bfe, and a non-packed "slow" instruction of one wavefront co-issues with a "fast" one of another
+// (profiles/r02_valu_issue_rate.md, result 2: v_max_i32 next to v_add_u32 = full overlap) -- which no single wavefront
+// can do for itself.  The register allocation is held between a third and a half of the SIMD's 512-entry file, so that
+// exactly two of these wavefronts fit a SIMD wherever the dispatcher puts them (launch = 2 x SIMDs wavefronts): the
+// strip chain runs at the speed of its slowest member, a SIMD with three would hold everybody up.
+#ifndef SW32_WAVES_PER_SIMD
+#define SW32_WAVES_PER_SIMD 2
+#endif
 template <int R, bool SW, bool PROFILE, bool TRACK>
-__global__ void __launch_bounds__(64) sw_strip_kernel(const KernelArgs* __restrict__ ap) {
+__global__ void __launch_bounds__(64)
+#if SW32_WAVES_PER_SIMD == 2
+__attribute__((amdgpu_waves_per_eu(2, 2)))
+#endif
+sw_strip_kernel(const KernelArgs* __restrict__ ap) {
     __shared__ WaveLds lds_store;
     WaveLds* lds = &lds_store;
     const int lane = threadIdx.x;
     const UniformArgs a = uniform_args(ap);
     const int num_strips = a->num_strips;
+#if SW32_WAVES_PER_SIMD == 2
+    // vector + accumulation registers together in (170, 256]: R = 4 uses ~85 vector registers, R = 8 ~135, R = 16 ~250
+    if (R == 4) asm volatile("" ::: "a127");
+    else if (R == 8) asm volatile("" ::: "a63");
+#else
     // one wavefront per SIMD, enforced: see sw_kernel_pk16.inc
     asm volatile("" ::: "a255");
+#endif
     for (;;) {
         const int s = __builtin_amdgcn_readfirstlane(claim_strip_common(ap, lane, 64 * R));
         if (s >= num_strips) break;
@@ -411,6 +430,8 @@ hipError_t launch_strip_kernel(const KernelArgs& a, KernelArgs* dargs, int rows_
     default: return hipErrorInvalidValue;
     }
 }
+
+int strip_kernel_waves_per_simd() { return SW32_WAVES_PER_SIMD; }
 
 hipError_t launch_fill_bus(int2* bus, int n, int init_type, int start_offset, hipStream_t stream) {
     int blocks = (n + 255) / 256;

@@ -176,7 +176,8 @@ def _worker_prune(rank, world, port, m, n, q):
                               special_row_sink=lambda dp, c0, cells: rows.__setitem__(dp, (c0.copy(), cells.copy())))
             st = al.getStatistics()
             out[mode] = dict(best=tuple(runner.reduce_best(best)), rows=rows, pruned=int(st["pruned_cells"]),
-                             cells=int(st["cells"]), hints=runner.hints, special=list(runner.special_rows))
+                             cells=int(st["cells"]), hints=runner.hints, special=list(runner.special_rows),
+                             restarts=runner.restarts, kernel=st["profile_kernel"])
             dist.barrier()
             al.close()
         q.put((rank, out))
@@ -194,7 +195,7 @@ def test_chain_of_bands_prunes_with_the_shared_best_and_keeps_special_rows(pkg, 
     bounds of the exact ones with the same maximum.  Both transports."""
     import numpy as np
     from masa_cudalign_amd.bands import band_limits
-    m, n, world = 36000, 40000, 4
+    m, n, world = 72000, 80000, 4       # scores up to ~60 000: the later bands' first columns lie far above 2^15
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -209,7 +210,7 @@ def test_chain_of_bands_prunes_with_the_shared_best_and_keeps_special_rows(pkg, 
     ref = oracle.stage1(s0, s1)
     want = (ref["best"][0] - 1, ref["best"][1] - 1, ref["best"][2])
     lim = band_limits(n, [1] * world)
-    dps = [8192, 16384, 24576, 32768]
+    dps = list(range(8192, m, 8192))
     for mode in ("plain", "pruned", "pruned_host"):
         assert all(res[r][mode]["best"] == want for r in range(world)), (mode, [res[r][mode]["best"] for r in range(world)], want)
         assert all(res[r][mode]["special"] == dps for r in range(world)), mode
@@ -222,6 +223,10 @@ def test_chain_of_bands_prunes_with_the_shared_best_and_keeps_special_rows(pkg, 
         for mode in ("pruned", "pruned_host"):
             got = np.concatenate([res[r][mode]["rows"][dp][1] for r in range(world)])
             assert np.all(got[:, 0] <= row[1:, 0]) and got[:, 0].max() == row[1:, 0].max(), (mode, dp)
+    # every band stayed on the packed kernel: a boundary column deep inside a long alignment (scores far above the
+    # 16-bit range, relative to a window that follows them) is not an overflow
+    for mode in ("plain", "pruned", "pruned_host"):
+        assert all(res[r][mode]["restarts"] == 0 and res[r][mode]["kernel"] == 2 for r in range(world)), (mode, [(res[r][mode]["restarts"], res[r][mode]["kernel"]) for r in range(world)])
     assert all(res[r]["plain"]["pruned"] == 0 for r in range(world))
     for mode in ("pruned", "pruned_host"):
         assert all(res[r][mode]["pruned"] > 0 for r in range(1, world)), (mode, [res[r][mode]["pruned"] for r in range(world)])
@@ -258,6 +263,7 @@ def test_running_best_travels_through_the_ports_in_both_directions(pkg, oracle):
             while not al.streamPoll()[1]:
                 pass
             best, _ = al.streamEnd()
+            assert al.getStatistics()["profile_kernel"] == 2          # the packed kernel took the band (no overflow report)
             return best, int(al.getStatistics()["pruned_cells"])
         finally:
             os.environ.pop("MI355SW_NO_SHARED_BEST", None)
