@@ -214,7 +214,7 @@ static __device__ __attribute__((noinline, unused)) void complete_strip_common(c
 // `dargs` = device copy of the argument block (the launcher uploads `a` into it on `stream`)
 hipError_t launch_strip_kernel(const KernelArgs& a, KernelArgs* dargs, int rows_per_lane, int grid, hipStream_t stream,
                                bool sw, bool profile, bool track);
-int strip_kernel_waves_per_simd();   // int32 family: wavefronts of one launch that share a SIMD (2; the packed kernels: 1)
+int strip_kernel_waves_per_simd(int rows_per_lane);   // int32 family: wavefronts of one launch that share a SIMD (2 for 256/512-row strips; the packed kernels: 1)
 // packed 16-bit SW kernel (sw_kernel_pk16.inc, instantiated by sw_kernel_pk16_{a,b,c}.hip): strip height = 128*rows_per_half
 hipError_t launch_strip_kernel_pk16(const KernelArgs& a, KernelArgs* dargs, int rows_per_half, int grid, hipStream_t stream, bool track, bool sw);
 // stage 4 (stage4.hip): Myers-Miller refinement of a crosspoint list, batched on the GPU

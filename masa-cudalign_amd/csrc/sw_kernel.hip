@@ -350,13 +350,16 @@ __device__ __attribute__((noinline)) void process_strip(const KernelArgs* ap, co
 // can do for itself.  The register allocation is held between a third and a half of the SIMD's 512-entry file, so that
 // exactly two of these wavefronts fit a SIMD wherever the dispatcher puts them (launch = 2 x SIMDs wavefronts): the
 // strip chain runs at the speed of its slowest member, a SIMD with three would hold everybody up.
+// Measured (tools/int32_perf.py, 4 M x 3 M SW, GCUPS one / two wavefronts per SIMD): 256-row strips 1543 / 2244 (related),
+// 512-row 1779 / 2060 (related), 2023(1024-row) / 2468 (unrelated); 1024-row strips need 248 registers and LOSE with two
+// (1718 / 1486): they keep a SIMD to themselves, and the runtime prefers the short strips for this family.
 #ifndef SW32_WAVES_PER_SIMD
 #define SW32_WAVES_PER_SIMD 2
 #endif
 template <int R, bool SW, bool PROFILE, bool TRACK>
 __global__ void __launch_bounds__(64)
 #if SW32_WAVES_PER_SIMD == 2
-__attribute__((amdgpu_waves_per_eu(2, 2)))
+__attribute__((amdgpu_waves_per_eu(R == 16 ? 1 : 2, R == 16 ? 1 : 2)))
 #endif
 sw_strip_kernel(const KernelArgs* __restrict__ ap) {
     __shared__ WaveLds lds_store;
@@ -368,6 +371,7 @@ sw_strip_kernel(const KernelArgs* __restrict__ ap) {
     // vector + accumulation registers together in (170, 256]: R = 4 uses ~85 vector registers, R = 8 ~135, R = 16 ~250
     if (R == 4) asm volatile("" ::: "a127");
     else if (R == 8) asm volatile("" ::: "a63");
+    else asm volatile("" ::: "a255");               // 1024-row strips: one wavefront per SIMD, as the packed kernels
 #else
     // one wavefront per SIMD, enforced: see sw_kernel_pk16.inc
     asm volatile("" ::: "a255");
@@ -431,7 +435,7 @@ hipError_t launch_strip_kernel(const KernelArgs& a, KernelArgs* dargs, int rows_
     }
 }
 
-int strip_kernel_waves_per_simd() { return SW32_WAVES_PER_SIMD; }
+int strip_kernel_waves_per_simd(int rows_per_lane) { return (SW32_WAVES_PER_SIMD == 2 && rows_per_lane < 16) ? 2 : 1; }
 
 hipError_t launch_fill_bus(int2* bus, int n, int init_type, int start_offset, hipStream_t stream) {
     int blocks = (n + 255) / 256;

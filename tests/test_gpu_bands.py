@@ -207,15 +207,16 @@ def test_chain_of_bands_prunes_with_the_shared_best_and_keeps_special_rows(pkg, 
         p.join(timeout=60)
         assert p.exitcode == 0
     s0, s1 = pkg.seqgen.related_pair(m, n, cfg=47)
-    ref = oracle.stage1(s0, s1)
+    ref = oracle.stage1(s0, s1, special_row_interval=8192, block_h=1024, block_w=1024)     # one pass: best + every special row
     want = (ref["best"][0] - 1, ref["best"][1] - 1, ref["best"][2])
     lim = band_limits(n, [1] * world)
     dps = list(range(8192, m, 8192))
+    assert ref["special_row_ids"] == dps
     for mode in ("plain", "pruned", "pruned_host"):
         assert all(res[r][mode]["best"] == want for r in range(world)), (mode, [res[r][mode]["best"] for r in range(world)], want)
         assert all(res[r][mode]["special"] == dps for r in range(world)), mode
-    for dp in dps:
-        row = oracle.stage1(s0[:dp], s1, want_last_row=True)["last_row"]
+    for k, dp in enumerate(dps):
+        row = ref["special_rows"][k]                     # cell 0 = first-column cell with f = -INF
         got = np.concatenate([res[r]["plain"]["rows"][dp][1] for r in range(world)])
         assert np.array_equal(got, row[1:]), dp
         for r in range(world):
