@@ -165,6 +165,17 @@ int mi355sw_unset_sequences(mi355sw_handle* h);
 int mi355sw_align_partition(mi355sw_handle* h, const mi355sw_partition* partition,
                             const mi355sw_manager* manager, void* user);
 
+/* Several independent partitions in ONE kernel launch -- the partitions stage 3 refines (M/stage3/sw_stage3.cpp:210-262
+ * processes them one alignPartition call after the other; each is a tall, narrow NW partition that stops as soon as its
+ * goal shows up: milliseconds of critical path on a handful of wavefronts, the rest of the GPU idle).  Semantics: as if
+ * mi355sw_align_partition(h, &partitions[k], managers[k], users[k]) had been called for every k -- same hooks, same
+ * order PER partition, all from the calling thread -- but the partitions run side by side, so the calls of different
+ * managers interleave.  Every partition needs its own manager state (borders, goal, sinks).  Partitions the batch
+ * cannot take (more than 14 common byte values, >= 32 Mi rows, block pruning or block scores wanted, an overflow report
+ * of the packed kernel) are run one by one after the others.  mi355sw_get_stats: sums over the call. */
+int mi355sw_align_partitions(mi355sw_handle* h, int32_t count, const mi355sw_partition* partitions,
+                             const mi355sw_manager* const* managers, void* const* users);
+
 /* AbstractBlockProcessor::processBlock (M/libmasa/processors/AbstractBlockProcessor.hpp:27-37,
  * semantics CPUBlockProcessor.cpp:95-112): row[k] = (H,F) of (i0-1,j0+k) in/out, col[0] = diagonal
  * H, col[k+1] = (H,E) of (i0+k,j0-1) in/out; returns the first strict maximum in row-major order. */

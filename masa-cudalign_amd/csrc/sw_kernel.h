@@ -114,11 +114,10 @@ __device__ __forceinline__ int poll_system(const int* p) { return rfl(__hip_atom
 // memory the neighbour band's PCIe stores crawled), then for the counter.  The budget is wall time
 // (s_memrealtime, 100 MHz), not a spin count; when it runs out the strip is given up (abort + error 2) instead
 // of being computed on rows that never came.
-static __device__ __attribute__((noinline, unused)) int claim_strip_common(const KernelArgs* ap, const int lane, const int strip_rows) {
+// the wait of a claimed strip for first-column rows that somebody else delivers (see claim_strip_common)
+static __device__ __attribute__((noinline, unused)) void wait_first_column_common(const KernelArgs* ap, const int s_in, const int lane, const int strip_rows) {
     const UniformArgs a = uniform_args(ap);
-    int s = 0;
-    if (lane == 0) s = atomicAdd(a->ticket, 1);
-    s = sync::rfl(s);
+    const int s = sync::rfl(s_in);
     if (a->first_col_ready != nullptr && s < a->num_strips) {
         const long long t0 = __builtin_amdgcn_s_memrealtime();
         const long long budget = a->wait_ticks;
@@ -150,6 +149,14 @@ static __device__ __attribute__((noinline, unused)) int claim_strip_common(const
         if (lane == 0 && a->wait_acc != nullptr) atomicAdd(a->wait_acc, (unsigned long long) (__builtin_amdgcn_s_memrealtime() - t0));
         __builtin_amdgcn_wave_barrier();
     }
+}
+
+static __device__ __attribute__((noinline, unused)) int claim_strip_common(const KernelArgs* ap, const int lane, const int strip_rows) {
+    const UniformArgs a = uniform_args(ap);
+    int s = 0;
+    if (lane == 0) s = atomicAdd(a->ticket, 1);
+    s = sync::rfl(s);
+    wait_first_column_common(ap, s, lane, strip_rows);
     return s;
 }
 
@@ -210,6 +217,18 @@ static __device__ __attribute__((noinline, unused)) void complete_strip_common(c
     __builtin_amdgcn_wave_barrier();
 }
 #endif
+
+// Several partitions in ONE launch (mi355sw_align_partitions): every partition keeps its own argument block, buses,
+// progress words and control block; the launch only shares the wavefronts.  Tickets are handed out in the order of
+// `map` -- strip 0 of every partition, then strip 1 of every partition, ... -- so a strip's predecessor always holds
+// an earlier ticket (claimed by a wavefront that is running): forward progress for any grid size, as with one partition.
+struct BatchArgs {
+    const KernelArgs* const* args;   // [partitions] device argument blocks
+    const int2* map;                 // [total] ticket -> (partition, strip)
+    int total;
+    int* ticket;
+};
+hipError_t launch_batch_kernel_pk16(const BatchArgs* dbatch, int rows_per_half, int grid, hipStream_t stream, bool track, bool sw);
 
 // `dargs` = device copy of the argument block (the launcher uploads `a` into it on `stream`)
 hipError_t launch_strip_kernel(const KernelArgs& a, KernelArgs* dargs, int rows_per_lane, int grid, hipStream_t stream,

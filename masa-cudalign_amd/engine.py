@@ -142,7 +142,7 @@ class ManagerTable(C.Structure):
 ABI_SYMBOLS = [
     "mi355sw_create", "mi355sw_destroy", "mi355sw_last_error", "mi355sw_abi_version", "mi355sw_build_id",
     "mi355sw_get_capabilities", "mi355sw_get_score_parameters",
-    "mi355sw_set_sequences", "mi355sw_unset_sequences", "mi355sw_align_partition",
+    "mi355sw_set_sequences", "mi355sw_unset_sequences", "mi355sw_align_partition", "mi355sw_align_partitions",
     "mi355sw_process_block", "mi355sw_match_last_column", "mi355sw_progress",
     "mi355sw_processed_cells", "mi355sw_get_stats",
     "mi355sw_stream_begin", "mi355sw_stream_feed_column", "mi355sw_stream_poll",
@@ -202,6 +202,7 @@ def load_library():
     lib.mi355sw_set_sequences.argtypes = [H, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]
     lib.mi355sw_unset_sequences.argtypes = [H]
     lib.mi355sw_align_partition.argtypes = [H, C.POINTER(Partition), C.POINTER(ManagerTable), C.c_void_p]
+    lib.mi355sw_align_partitions.argtypes = [H, C.c_int32, C.POINTER(Partition), C.POINTER(C.POINTER(ManagerTable)), C.POINTER(C.c_void_p)]
     lib.mi355sw_process_block.argtypes = [H, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                           C.c_int32, C.POINTER(Score)]
     lib.mi355sw_match_last_column.argtypes = [H, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.POINTER(MatchResult)]
@@ -341,6 +342,23 @@ class MI355Aligner:
         if getattr(manager, "_callback_error", None):
             raise manager._callback_error
         del keep
+
+    def alignPartitions(self, partitions, managers):
+        """mi355sw_align_partitions: independent partitions side by side in one kernel launch; managers[k] is served
+        exactly as alignPartition(partitions[k], managers[k]) would serve it, the calls of different managers interleave"""
+        n = len(partitions)
+        assert n == len(managers)
+        if n == 0:
+            return
+        parts = (Partition * n)(*[Partition(p.i0, p.j0, p.i1, p.j1) for p in partitions])
+        tables, keeps = zip(*[make_manager_table(m) for m in managers])
+        ptrs = (C.POINTER(ManagerTable) * n)(*[C.pointer(t) for t in tables])
+        rc = self._lib.mi355sw_align_partitions(self._h, n, parts, ptrs, None)
+        for m in managers:
+            if getattr(m, "_callback_error", None):
+                raise m._callback_error
+        self._check(rc, "alignPartitions")
+        del keeps
 
     def processBlock(self, row, col, i0, j0, i1, j1, recurrence_type):
         """AbstractBlockProcessor::processBlock: row (n,2), col (m+1,2) int32, updated in place."""

@@ -462,10 +462,14 @@ class AlignerManager:
         self.goal_score, self.goal_location = -INF, AT_NOWHERE
 
     # -- one partition (:89-166) -------------------------------------------------------------------------------
-    def alignPartition(self, partition, start_type):
+    def prepareAlign(self, partition, start_type):
+        """everything of alignPartition (:89-166) up to the call of the aligner: returns the partition to hand to the
+        aligner (sequence-relative), or None when there is nothing for it to do (no cells, or the goal is met by a
+        border-long gap).  alignPartition = prepareAlign + aligner.alignPartition; stage 3 collects the prepared
+        partitions of many walks and hands them over together (MI355Aligner.alignPartitions)."""
         self.partition, self.start_type, self.found = partition, start_type, False
         if partition.getWidth() == 0 or partition.getHeight() == 0:
-            return
+            return None
         self.last_column_pos = self.last_row_pos = 0
         self.active = True
         if self.sra is not None:
@@ -481,10 +485,22 @@ class AlignerManager:
             if r is not None:
                 self.next_crosspoint = (partition.i1, partition.j0, r, 2)
                 self.active = False
-        if self.active:
-            adj = Partition(partition.i0 - self.seq0_offset, partition.j0 - self.seq1_offset,
-                            partition.i1 - self.seq0_offset, partition.j1 - self.seq1_offset)
+        if not self.active:
+            return None
+        return Partition(partition.i0 - self.seq0_offset, partition.j0 - self.seq1_offset,
+                         partition.i1 - self.seq0_offset, partition.j1 - self.seq1_offset)
+
+    def alignPartition(self, partition, start_type):
+        adj = self.prepareAlign(partition, start_type)
+        if adj is not None:
             self.aligner.alignPartition(adj, self)
+
+    def clone(self):
+        """another manager on the same aligner and sequences, with state of its own: one per walk that runs side by side"""
+        c = AlignerManager(self.aligner)
+        c.recurrence, c.block_pruning, c.special_row_interval = self.recurrence, self.block_pruning, self.special_row_interval
+        c.seq0_offset, c.seq1_offset = self.seq0_offset, self.seq1_offset
+        return c
 
     def isFoundCrosspoint(self):
         return self.found

@@ -31,9 +31,9 @@ def _as_u8(seq):
     return np.frombuffer(bytes(seq), dtype=np.uint8) if isinstance(seq, (bytes, bytearray)) else np.asarray(seq, dtype=np.uint8)
 
 
-def find_next_crosspoint(mgr, area, c0, c1, alignment_start, must_find=True, goal_location=None):
-    """sw_stage2.cpp:49-129 / sw_stage3.cpp:49-122: aligns partition c0 -> c1 (both in the coordinates of the running
-    orientation), returns the crosspoint where the goal c0.score is met on the last column / last row / inside"""
+def prepare_next_crosspoint(mgr, area, c0, c1, alignment_start, must_find=True, goal_location=None):
+    """the set-up of find_next_crosspoint: goal, borders and special-rows partition of the sweep c0 -> c1.  Returns
+    (special-rows partition, partition for the aligner or None if the manager met the goal without it)."""
     first_row = InitialCellsReader(0 if c0.type == TYPE_GAP_1 else GAP_OPEN, GAP_EXT)
     first_col = InitialCellsReader(0 if c0.type == TYPE_GAP_2 else GAP_OPEN, GAP_EXT)
     if not must_find:
@@ -49,10 +49,15 @@ def find_next_crosspoint(mgr, area, c0, c1, alignment_start, must_find=True, goa
     part.set_first_row_reader(first_row)
     mgr.setSpecialRowsPartition(part)
     try:
-        mgr.alignPartition(Partition(c0.i, c0.j, c1.i, c1.j), c0.type)
+        adj = mgr.prepareAlign(Partition(c0.i, c0.j, c1.i, c1.j), c0.type)
     except BaseException:
         part.close()
         raise
+    return part, adj
+
+
+def conclude_next_crosspoint(mgr, area, part, c0, c1, must_find=True):
+    """what find_next_crosspoint does once the aligner is through with the sweep"""
     if not must_find:
         part.close()
         return c1.copy()
@@ -63,6 +68,19 @@ def find_next_crosspoint(mgr, area, c0, c1, alignment_start, must_find=True, goa
     i, j, score, typ = mgr.getNextCrosspoint()
     area.truncate_partition(part, i, j)
     return Crosspoint(i, j, score, typ)
+
+
+def find_next_crosspoint(mgr, area, c0, c1, alignment_start, must_find=True, goal_location=None):
+    """sw_stage2.cpp:49-129 / sw_stage3.cpp:49-122: aligns partition c0 -> c1 (both in the coordinates of the running
+    orientation), returns the crosspoint where the goal c0.score is met on the last column / last row / inside"""
+    part, adj = prepare_next_crosspoint(mgr, area, c0, c1, alignment_start, must_find, goal_location)
+    if adj is not None:
+        try:
+            mgr.aligner.alignPartition(adj, mgr)
+        except BaseException:
+            part.close()
+            raise
+    return conclude_next_crosspoint(mgr, area, part, c0, c1, must_find)
 
 
 def stage2(aligner, seq0, seq1, work, alignment_start=AT_ANYWHERE, sra_limit=0, ident=0, bounds=None, ram_limit=0,

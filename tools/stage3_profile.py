@@ -1,0 +1,37 @@
+"""Where a native stage-3 sweep spends its time: stages 1-2 as usual, stage 3 under cProfile.
+    python tools/stage3_profile.py M N"""
+import cProfile, pstats, io, os, sys, tempfile, time, shutil
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import __graft_entry__ as g
+pkg = g.load_package()
+from masa_cudalign_amd import fasta
+from masa_cudalign_amd.stage1 import stage1
+from masa_cudalign_amd.stage2 import stage2
+from masa_cudalign_amd.stage3 import stage3
+import numpy as np
+m, n = int(sys.argv[1]), int(sys.argv[2])
+s0, s1 = pkg.seqgen.related_pair(m, n, cfg=2)
+work = tempfile.mkdtemp(prefix="s3prof_")
+limit = min(max(200 * 1024, (m // 8192 + 1) * n * 8), 4 << 30)
+al = pkg.MI355Aligner(device=0)
+areas = {}
+try:
+    t = time.time(); r1 = stage1(al, s0, s1, work, sra_limit=limit, areas=areas); print("stage1 %.2f s best %s" % (time.time() - t, r1["best"]))
+    t = time.time(); r2 = stage2(al, s0, s1, work, sra_limit=limit, areas=areas); print("stage2 %.2f s, %d crosspoints" % (time.time() - t, len(r2["crosspoints"])))
+    acc = {"kernel_ms": 0.0, "calls": 0, "cells": 0, "rows": 0, "cols": 0, "launches": 0}
+    orig = al.alignPartition
+    def counted(part, mgr):
+        orig(part, mgr)
+        st = al.getStatistics()
+        acc["kernel_ms"] += st["kernel_ms"]; acc["calls"] += 1; acc["cells"] += st["cells"]
+        acc["rows"] += part.i1 - part.i0; acc["cols"] += part.j1 - part.j0; acc["launches"] += st["kernel_launches"]
+    al.alignPartition = counted
+    pr = cProfile.Profile()
+    t = time.time()
+    pr.enable(); r3 = stage3(al, s0, s1, work, sra_limit=limit, areas=areas); pr.disable()
+    print("stage3 %.2f s, rounds %s" % (time.time() - t, r3["rounds"]))
+    print("engine: %d calls, kernel %.1f ms total (%.2f ms per call), mean partition %d x %d, %.1f Gcells" % (
+        acc["calls"], acc["kernel_ms"], acc["kernel_ms"] / max(1, acc["calls"]), acc["rows"] // max(1, acc["calls"]), acc["cols"] // max(1, acc["calls"]), acc["cells"] / 1e9))
+    out = io.StringIO(); pstats.Stats(pr, stream=out).sort_stats("cumulative").print_stats(8); print(out.getvalue()[:2500])
+finally:
+    al.close(); shutil.rmtree(work, ignore_errors=True)
