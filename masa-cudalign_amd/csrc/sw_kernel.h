@@ -75,6 +75,9 @@ struct KernelArgs {
     int* host_best_report;       // pinned host word: the running best as of the last completed strip, or nullptr
     unsigned long long* wait_acc; // 10 ns ticks the wavefronts spent in claim_strip_common waiting for first-column rows
                                  // that somebody else delivers (host or neighbour GPU), summed over the wavefronts; or nullptr
+    int mix_first;               // strips [0, mix_first) have the kernel's first height, the rest its second (mixed-height
+                                 // launches, sw_strip_kernel_pk16_mixed); INT_MAX for the ordinary kernels
+    int strip_row0_b;            // DP row of strip s >= mix_first = strip_row0_b + s * (second height)
     const int* gbest_in;         // where the strips READ the running best from: gbest itself, or a word that stays at -INF
                                  // when every strip record must be that strip's own exact best (block scores) instead
                                  // of "nothing below what is already known elsewhere"
@@ -228,6 +231,9 @@ struct BatchArgs {
     int total;
     int* ticket;
 };
+// two strip heights in one launch: strips [0, a.mix_first) are 128*rows_per_half_a rows tall, the others 128*rows_per_half_b
+hipError_t launch_strip_kernel_pk16_mixed(const KernelArgs& a, KernelArgs* dargs, int rows_per_half_a, int rows_per_half_b, int grid,
+                                          hipStream_t stream, bool track, bool sw);
 hipError_t launch_batch_kernel_pk16(const BatchArgs* dbatch, int rows_per_half, int grid, hipStream_t stream, bool track, bool sw);
 
 // `dargs` = device copy of the argument block (the launcher uploads `a` into it on `stream`)
