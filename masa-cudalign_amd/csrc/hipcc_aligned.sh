@@ -2,7 +2,7 @@
 # hipcc_aligned.sh SRC.hip OUT.o [compiler flags...]
 # Compiles one HIP translation unit for gfx950 like `hipcc -c`, with one extra step between the compiler and the
 # assembler: align8.py keeps every 8-byte instruction 8-byte aligned (see its header for the measurement).
-#   device:  hipcc -S  ->  assemble (sizes)  ->  align8.py  ->  assemble  ->  lld  ->  clang-offload-bundler
+#   device:  hipcc -S  ->  strip_pk_nops.py  ->  assemble (sizes)  ->  align8.py  ->  assemble  ->  lld  ->  clang-offload-bundler
 #   host:    hipcc --cuda-host-only with the bundle embedded (-fcuda-include-gpubinary)
 set -e
 src=$1; out=$2; shift 2
@@ -13,7 +13,9 @@ tmp=$(dirname "$out")/$(basename "$out" .o).al
 mkdir -p "$tmp"
 # 15-bit branch range at compile time: the padding added afterwards can never push a short branch out of its
 # real 16-bit range
-hipcc --offload-arch=$ARCH "$@" -mllvm -amdgpu-s-branch-bits=15 --cuda-device-only -S "$src" -o "$tmp/dev.s"
+hipcc --offload-arch=$ARCH "$@" -mllvm -amdgpu-s-branch-bits=15 --cuda-device-only -S "$src" -o "$tmp/dev.raw.s"
+# wait states the hardware does not need (see strip_pk_nops.py); ALIGN8_KEEP_PK_NOPS=1 keeps the compiler's
+if [ -z "$ALIGN8_KEEP_PK_NOPS" ]; then python3 "$here/strip_pk_nops.py" "$tmp/dev.raw.s" "$tmp/dev.s"; else cp "$tmp/dev.raw.s" "$tmp/dev.s"; fi
 $LLVM/clang -target amdgcn-amd-amdhsa -mcpu=$ARCH -c -x assembler "$tmp/dev.s" -o "$tmp/dev.o"
 $LLVM/llvm-objdump -d "$tmp/dev.o" > "$tmp/dev.objdump"
 python3 "$here/align8.py" "$tmp/dev.s" "$tmp/dev.objdump" "$tmp/dev.al.s"
