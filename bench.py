@@ -46,11 +46,13 @@ PMC_INDEX = os.path.join(ROOT, "profiles", "pmc_index.json")
 def kernel_build_id():
     """identity of the device code of the LOADED library (mi355sw_build_id: the hash of csrc/ compiled into it).  PMC
     figures are quoted only when library id = id of the sources in the tree = key of profiles/pmc_index.json."""
+    graft.load_package()
     from masa_cudalign_amd import engine
     return engine.library_build_id()
 
 
 def build_identity():
+    graft.load_package()
     from masa_cudalign_amd import engine
     lib, src = engine.library_build_id(), engine.source_build_id()
     return {"library": lib, "sources": src, "stale_library": lib != src}
@@ -391,14 +393,18 @@ def target_shape(pkg, device, check=True):
 
 
 def _valu(st, band_cells, k_ms, pmc):
-    if not pmc or not pmc.get("valu_per_step"):
-        return {"valu_instr_per_step": None, "frac": None, "peak_wave_instr_per_s": VALU_PEAK_WAVE_INSTR,
+    """the unit that binds this kernel: vector instructions issued per second (SQ_INSTS_VALU of this build's launch, per
+    wavefront) against the SIMDs' issue rate for the packed instruction class"""
+    if not pmc or not pmc.get("valu_per_launch"):
+        return {"valu_instr_per_launch": None, "frac": None, "peak_wave_instr_per_s": VALU_PEAK_WAVE_INSTR,
                 "note": "SQ_INSTS_VALU not measured on this kernel build (profiles/pmc_index.json has no entry)"}
-    per_step = pmc["valu_per_step"]
-    achieved = band_cells / st["strip_rows"] * per_step / (k_ms * 1e-3)
-    return {"valu_instr_per_step": per_step, "cells_per_step": st["strip_rows"], "achieved_wave_instr_per_s": achieved,
-            "peak_wave_instr_per_s": VALU_PEAK_WAVE_INSTR, "frac": achieved / VALU_PEAK_WAVE_INSTR,
-            "source": pmc["source"], "peak_source": "profiles/r02_valu_issue_rate.md (v_pk_max_i16, 4 wavefronts per SIMD)"}
+    per_launch = pmc["valu_per_launch"]
+    achieved = per_launch / (k_ms * 1e-3)
+    return {"valu_instr_per_launch": per_launch, "valu_instr_per_cell": per_launch / band_cells,
+            "achieved_wave_instr_per_s": achieved, "peak_wave_instr_per_s": VALU_PEAK_WAVE_INSTR, "frac": achieved / VALU_PEAK_WAVE_INSTR,
+            "frac_of_one_instr_per_4_cycles": achieved / (256 * 4 * 2.38e9 / 4),
+            "source": pmc["source"], "peak_source": "profiles/r02_valu_issue_rate.md (v_pk_max_i16, 4 wavefronts per SIMD: 0.536 / ns / SIMD; "
+                                                  "a lone wavefront issues one per 4 cycles at 2.38 GHz = 0.595 / ns / SIMD)"}
 
 
 def _reduce_cpu(dist, best, world, device):
