@@ -19,11 +19,8 @@ Mi355Aligner::Mi355Aligner(int device, int rowsPerLane, int waves) : handle(NULL
     score_params.gap_ext = sp.gap_ext;
     params = new Mi355AlignerParameters();
     if (device >= 0) params->setGPU(device);
-    // one forked instance per GPU, seq1 split in proportion to compute units x clock (X/CUDAligner.cpp:63-66)
-    int weights[64];
-    const int gpus = Mi355AlignerParameters::deviceWeights(weights, 64);
-    if (gpus > 0) setForkCount(gpus, weights);
-    else setForkCount(1);
+    // fork weights are asked for lazily (getForkWeights): enumerating the GPUs costs a child process
+    weightsKnown = false;
     clearStatistics();
     progress[0] = 0;
 }
@@ -37,6 +34,19 @@ void Mi355Aligner::check(int rc, const char* what) {
         fprintf(stderr, "Mi355Aligner: %s failed (%d): %s\n", what, rc, handle ? mi355sw_last_error(handle) : "");
         exit(1);
     }
+}
+
+// one forked instance per GPU, seq1 split in proportion to compute units x clock (X/CUDAligner.cpp:63-66); only when
+// MASA-Core asks (--fork), and before it forks: the devices are enumerated in a throw-away child process
+const int* Mi355Aligner::getForkWeights() {
+    if (!weightsKnown) {
+        int weights[64];
+        const int gpus = Mi355AlignerParameters::deviceWeights(weights, 64);
+        if (gpus > 0) setForkCount(gpus, weights);
+        else setForkCount(1);
+        weightsKnown = true;
+    }
+    return AbstractAligner::getForkWeights();
 }
 
 aligner_capabilities_t Mi355Aligner::getCapabilities() {

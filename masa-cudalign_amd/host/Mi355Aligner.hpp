@@ -20,6 +20,7 @@ public:
 
     /* IAligner */
     virtual aligner_capabilities_t getCapabilities();
+    virtual const int* getForkWeights();          /* enumerates the GPUs on first use (a child process, bounded in time) */
     virtual const score_params_t* getScoreParameters();
     virtual IAlignerParameters* getParameters();
     virtual void initialize();
@@ -67,6 +68,7 @@ private:
     mi355sw_config config;
     score_params_t score_params;
     Mi355AlignerParameters* params;
+    bool weightsKnown;
     mutable char progress[256];
     long long statCells;
     long long statPruned;

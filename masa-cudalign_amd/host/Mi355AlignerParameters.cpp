@@ -4,6 +4,8 @@
 #include <getopt.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <poll.h>
+#include <signal.h>
 #include <sys/types.h>
 #include <sys/wait.h>
 #include <unistd.h>
@@ -92,10 +94,19 @@ int Mi355AlignerParameters::deviceWeights(int* weights, int max) {
         _exit(0);
     }
     close(fd[1]);
+    // bounded: a child that inherited a HIP runtime already initialised in this process (a second aligner, a library
+    // user) may never answer -- ten seconds, then it is killed and the caller falls back to one instance
     int count = 0, w = 0;
-    while (read(fd[0], &w, sizeof(w)) == (ssize_t) sizeof(w))
-        if (count < max) weights[count++] = w;
+    bool timed_out = false;
+    for (;;) {
+        struct pollfd pfd = {fd[0], POLLIN, 0};
+        const int pr = poll(&pfd, 1, 10000);
+        if (pr <= 0) { timed_out = true; break; }
+        if (read(fd[0], &w, sizeof(w)) != (ssize_t) sizeof(w)) break;
+        if (w > 0 && count < max) weights[count++] = w;        // a device that could not be queried gets no instance
+    }
     close(fd[0]);
+    if (timed_out) { kill(pid, SIGKILL); count = 0; }
     int status = 0;
     waitpid(pid, &status, 0);
     return count;

@@ -451,13 +451,18 @@ class Status:
         self.side = os.path.join(work, "status.mi355")
         self.stage, self.last_special_row, self.best = 1, 0, None
         self.value_best = None
+        self.value_key = None          # what the value belongs to: (i0, j0, i1, j1, alignment start, alignment end)
         self.loaded = False
         if os.path.exists(self.side):
             tok = open(self.side).read().split()
-            if len(tok) == 3:
+            if len(tok) >= 3:
                 self.value_best = (int(tok[0]), int(tok[1]), int(tok[2]))
-        if os.path.exists(self.file):
-            tok = open(self.file).read().split()
+            if len(tok) >= 9:
+                self.value_key = tuple(int(x) for x in tok[3:9])
+        # Status::load (Status.cpp:40-66) falls back to the temporary file when a kill fell between its write and the rename
+        src = self.file if os.path.exists(self.file) else (self.tmp if os.path.exists(self.tmp) else None)
+        if src is not None:
+            tok = open(src).read().split()
             if len(tok) >= 2:
                 self.stage, self.last_special_row = int(tok[0]), int(tok[1])
                 if len(tok) >= 5:
@@ -473,7 +478,10 @@ class Status:
     def save(self, best=None):
         if self.value_best is not None:
             with open(self.side + ".tmp", "w") as f:
-                f.write("%d %d %d\n" % self.value_best)
+                f.write("%d %d %d" % self.value_best)
+                if self.value_key is not None:
+                    f.write(" %d %d %d %d %d %d" % tuple(self.value_key))
+                f.write("\n")
             os.replace(self.side + ".tmp", self.side)
         if best is not None:
             self.best = tuple(int(x) for x in best)
@@ -481,6 +489,14 @@ class Status:
         with open(self.tmp, "w") as f:
             f.write("%d\n%d\n%d %d %d\n" % (self.stage, self.last_special_row, b[0], b[1], b[2]))
         os.replace(self.tmp, self.file)
+
+
+    def drop_value_best(self):
+        """stage 1 is complete: the value-only record of a two-phase run has served its purpose"""
+        self.value_best = self.value_key = None
+        for fn in (self.side, self.side + ".tmp"):
+            if os.path.exists(fn):
+                os.remove(fn)
 
 
 def flush_intervals(m, n, limit, max_deep=20):

@@ -105,10 +105,20 @@ def stage1(aligner, seq0, seq1, work, alignment_start=AT_ANYWHERE, alignment_end
             return {"best": status.best, "bests": _crosspoints_on_disk(work), "resumed_from": bi1, "seconds": 0.0, "gcups": 0.0, "already_done": True,
                     "special_rows": [r for r in part_sra.rows]}
         if last != bi0:
-            i0, row = part_sra.continue_from_last_row()
-            fc.read(None, i0 - bi0)                # firstColumnReader->read(NULL, lastRowId): rows since the border
-            fr = ArrayCellsReader(row)             # FileCellsReader(lastRowFilename): cell 0 = the corner of the rest
-            resumed_from = i0
+            # The status file is saved AFTER the row it belongs to has been renamed into place (two file writes): a kill
+            # in between leaves a row on disk whose best-score list was never saved.  The run continues from the row the
+            # status file knows (the rows below it are computed again and replace the files), and refuses to continue
+            # rows that have no status at all -- their best cells would be lost silently.
+            if not status.loaded:
+                raise RuntimeError("stage1: %s holds special rows but no status file: cannot resume (clean the work directory)" % work)
+            i0 = min(last, max(status.last_special_row, bi0))
+            if i0 != bi0:
+                row = part_sra.read_row(i0)
+                fc.read(None, i0 - bi0)                # firstColumnReader->read(NULL, lastRowId): rows since the border
+                fr = ArrayCellsReader(row)             # FileCellsReader(lastRowFilename): cell 0 = the corner of the rest
+                resumed_from = i0
+            else:
+                part_sra.set_border_markers(fr.getType(), 0, fc.getType(), 0)
         else:
             part_sra.set_border_markers(fr.getType(), 0, fc.getType(), 0)
     else:
@@ -127,6 +137,11 @@ def stage1(aligner, seq0, seq1, work, alignment_start=AT_ANYWHERE, alignment_end
     if status.loaded and status.best is not None and status.best[0] >= 0:
         mgr.best_list.add(*status.best)            # Status::load -> bestScoreList->add (Status.cpp:60-64)
     status.stage = 1
+    # the best strip VALUE a two-phase run left (status.mi355) only counts for the run that continues THAT partition
+    key = (bi0, bj0, bi1, bj1, int(alignment_start), int(alignment_end))
+    if resumed_from is None or status.value_key != key:
+        status.value_best = None
+    status.value_key = key
     prefix_value = status.value_best            # left by the run(s) this one continues: strips above row i0
     aligner.setSequences(v0, v1)
     t0 = time.time()
@@ -172,6 +187,7 @@ def stage1(aligner, seq0, seq1, work, alignment_start=AT_ANYWHERE, alignment_end
     status.stage = 2
     if part_sra is not None:
         status.last_special_row = part_sra.last_row_id()
+    status.drop_value_best()
     status.save(best)
     bests = mgr.best_list.all() if hasattr(mgr.best_list, "all") else ([tuple(best)] if best[0] >= 0 else [])
     for k, b in enumerate(bests):                   # sw_stage1.cpp:481-492: one file per entry of the list
