@@ -150,6 +150,12 @@ int mi355sw_abi_version(void);
  * build recipe (csrc/build_id.py).  Measurements (rocprof counters) are keyed by it. */
 const char* mi355sw_build_id(void);
 
+/* Strip height of the partitions that follow (mi355sw_config.rows_per_lane; 0 = back to the cost model).  The cost model
+ * minimises the time of a FULL sweep; a caller that knows its partitions will be stopped early by their goal (stage 2:
+ * tall partitions, the goal a few hundred thousand rows down) asks for short strips instead -- the first strip's sweep
+ * and one hop per strip down to the goal row are all that such a partition costs. */
+int mi355sw_set_rows_per_lane(mi355sw_handle* h, int32_t rows_per_lane);
+
 /* IAligner::getCapabilities (IAligner.hpp:159; X/CUDAligner.cpp:87-111) */
 int mi355sw_get_capabilities(mi355sw_handle* h, mi355sw_capabilities* out);
 /* IAligner::getScoreParameters (IAligner.hpp:177; X/CUDAligner.cpp:56-59): +1/-3/-3/-2 */

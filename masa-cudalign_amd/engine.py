@@ -141,7 +141,7 @@ class ManagerTable(C.Structure):
 # every symbol include/mi355sw.h declares (tests check the .so exports all of them)
 ABI_SYMBOLS = [
     "mi355sw_create", "mi355sw_destroy", "mi355sw_last_error", "mi355sw_abi_version", "mi355sw_build_id",
-    "mi355sw_get_capabilities", "mi355sw_get_score_parameters",
+    "mi355sw_get_capabilities", "mi355sw_get_score_parameters", "mi355sw_set_rows_per_lane",
     "mi355sw_set_sequences", "mi355sw_unset_sequences", "mi355sw_align_partition", "mi355sw_align_partitions",
     "mi355sw_process_block", "mi355sw_match_last_column", "mi355sw_progress",
     "mi355sw_processed_cells", "mi355sw_get_stats",
@@ -199,6 +199,7 @@ def load_library():
     lib.mi355sw_build_id.restype = C.c_char_p
     lib.mi355sw_get_capabilities.argtypes = [H, C.POINTER(Capabilities)]
     lib.mi355sw_get_score_parameters.argtypes = [H, C.POINTER(ScoreParams)]
+    lib.mi355sw_set_rows_per_lane.argtypes = [H, C.c_int32]
     lib.mi355sw_set_sequences.argtypes = [H, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]
     lib.mi355sw_unset_sequences.argtypes = [H]
     lib.mi355sw_align_partition.argtypes = [H, C.POINTER(Partition), C.POINTER(ManagerTable), C.c_void_p]
@@ -286,6 +287,7 @@ class MI355Aligner:
         self._lib = load_library()
         self._h = C.c_void_p()
         cfg = Config(device, rows_per_lane, waves, flags, max_special_bytes, block_score_columns, 0)
+        self._rows_per_lane = int(rows_per_lane)
         rc = self._lib.mi355sw_create(C.byref(cfg), C.byref(self._h))
         if rc != 0:
             self._h = C.c_void_p()
@@ -317,6 +319,14 @@ class MI355Aligner:
         c = Capabilities()
         self._check(self._lib.mi355sw_get_capabilities(self._h, C.byref(c)), "getCapabilities")
         return {k: getattr(c, k) for k, _ in Capabilities._fields_}
+
+    def setRowsPerLane(self, rows_per_lane):
+        """strip height (64 * rows_per_lane rows) of the partitions that follow; 0 = the engine's cost model"""
+        self._check(self._lib.mi355sw_set_rows_per_lane(self._h, int(rows_per_lane)), "setRowsPerLane")
+        self._rows_per_lane = int(rows_per_lane)
+
+    def getRowsPerLane(self):
+        return getattr(self, "_rows_per_lane", None)
 
     def getScoreParameters(self):
         p = ScoreParams()

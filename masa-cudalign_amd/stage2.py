@@ -122,6 +122,13 @@ def stage2(aligner, seq0, seq1, work, alignment_start=AT_ANYWHERE, sra_limit=0, 
     col_reader = row_reader = None
     partitions = 0
     crossing = True
+    # Stage 2's partitions are tall and stopped by their goal a few hundred thousand rows down: what they cost is the
+    # first strip's sweep plus one hop per strip down to the goal row, and 512-row strips halve that against the 2048-row
+    # strips the engine's cost model picks for a full sweep of such a shape (mi355sw_set_rows_per_lane).  Only when the
+    # caller left the height to the engine.
+    short_strips = hasattr(aligner, "setRowsPerLane") and aligner.getRowsPerLane() == 0
+    if short_strips:
+        aligner.setRowsPerLane(8)
     try:
         while crossing and part1 is not None:
             col_reader, row_reader = part1.first_column_reader, part1.first_row_reader
@@ -165,4 +172,6 @@ def stage2(aligner, seq0, seq1, work, alignment_start=AT_ANYWHERE, sra_limit=0, 
                 out.write(cp)
     finally:
         out.close()
+        if short_strips:
+            aligner.setRowsPerLane(0)
     return {"crosspoints": out.tuples(), "end": cp_r.astuple(), "partitions": partitions, "seconds": time.time() - t_start}

@@ -83,3 +83,44 @@ def test_align8_refuses_a_mismatching_object(tmp_path):
     p = subprocess.run(["python3", os.path.join(CSRC, "align8.py"), str(s), str(d), str(tmp_path / "o.s")],
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     assert p.returncode != 0 and b"align8" in p.stdout
+
+
+def test_only_wait_states_between_plain_packed_instructions_are_removed():
+    """csrc/strip_pk_nops.py: an `s_nop 0` goes only when BOTH neighbours are plain v_pk_* instructions; wait states in
+    front of DPP moves, after other instructions, longer ones, and ones next to a label stay"""
+    import sys
+    tmp = tempfile.mkdtemp(prefix="stripnops_")
+    try:
+        src, dst = os.path.join(tmp, "in.s"), os.path.join(tmp, "out.s")
+        open(src, "w").write("\n".join([
+            "\tv_pk_max_i16 v2, v2, v211",
+            "\ts_nop 0",                                   # 1: removed
+            "\tv_pk_max_i16 v2, v2, v1",
+            "\ts_nop 0",                                   # 2: removed (comment lines in between do not matter)
+            "\t; a comment",
+            "\tv_pk_add_u16 v37, v2, -3 op_sel_hi:[1,0]",
+            "\ts_nop 0",                                   # 3: kept, a DPP move follows
+            "\tv_mov_b32_dpp v8, v37 wave_shr:1 row_mask:0xf bank_mask:0xf",
+            "\tv_pk_add_u16 v3, v3, v4",
+            "\ts_nop 1",                                   # 4: kept, two wait states are somebody else's hazard
+            "\tv_pk_add_u16 v5, v3, v4",
+            "\tv_add_u32_e32 v6, v5, v4",
+            "\ts_nop 0",                                   # 5: kept, the producer is not a packed instruction
+            "\tv_pk_add_u16 v7, v6, v4",
+            "\ts_nop 0",                                   # 6: kept, a label (branch target) follows
+            ".LBB0_1:",
+            "\tv_pk_add_u16 v9, v7, v4",
+            ""]))
+        subprocess.check_call([sys.executable, os.path.join(CSRC, "strip_pk_nops.py"), src, dst], stderr=subprocess.DEVNULL)
+        out = open(dst).read()
+        assert out.count("s_nop 0") == 3 and out.count("s_nop 1") == 1
+        assert "v_pk_max_i16 v2, v2, v211\n\tv_pk_max_i16 v2, v2, v1\n\t; a comment\n\tv_pk_add_u16 v37" in out
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def test_library_carries_the_identity_of_its_sources(pkg):
+    """mi355sw_build_id() = csrc/build_id.py over the sources in the tree (a stale prebuilt library shows here)"""
+    pkg.build_library()
+    assert pkg.engine.library_build_id() == pkg.engine.source_build_id()
+    assert len(pkg.engine.library_build_id()) == 16
