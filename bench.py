@@ -308,6 +308,8 @@ def main():
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9
         band_cells = float(m) * float(j1 - j0)
         kname = "pk16" if st["profile_kernel"] == 2 else "int32"
+        # two strip heights in one launch (sw_strip_kernel_pk16_mixed): more strips than one height would need
+        mixed = st["profile_kernel"] == 2 and world == 1 and (st["strips"] - 1) * st["strip_rows"] >= m
         pmc = pmc_lookup(kname, m, j1 - j0, st["strip_rows"]) if world == 1 else None
         out = {
             "metric": "GCUPS (DP cells/sec) Stage-1", "value": gcups, "unit": "GCUPS",
@@ -338,9 +340,11 @@ def main():
                          "traffic": pmc["traffic_bytes"] if pmc else None,
                          "traffic_source": (pmc["source"] + " (rocprofv3 --pmc passes on this kernel build, bytes per launch)") if pmc
                                            else "not measured on this kernel build (profiles/pmc_index.json has no entry)",
-                         "kernel": "sw_strip_kernel_pk16" if st["profile_kernel"] == 2 else "sw_strip_kernel",
+                         "kernel": ("sw_strip_kernel_pk16_mixed<12,11,true,true>" if mixed else "sw_strip_kernel_pk16") if st["profile_kernel"] == 2 else "sw_strip_kernel",
+                         "strips": st["strips"],
                          "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_bytes,
-                         "note": "scan kernel: 17 B per column per %d-row strip; the binding unit is VALU issue" % st["strip_rows"]},
+                         "note": ("scan kernel: 17 B per column per strip (%d strips of %s rows); the binding unit is VALU issue"
+                                  % (st["strips"], "1536 and 1408" if mixed else str(st["strip_rows"])))},
             "valu_roofline": _valu(st, band_cells, k_ms, pmc),
         }
         # the extras must never cost the headline line: whatever goes wrong in them is reported inside the JSON
