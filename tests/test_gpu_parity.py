@@ -549,6 +549,34 @@ def test_two_phase_at_its_real_trigger(pkg, oracle, rel):
     assert ref["best"][0] == W and ref["best"][1] == j
 
 
+def test_packed_and_int32_agree_at_the_north_star_height(pkg, oracle):
+    """228 000 000 rows (the north star's height: 111 329 strips of 2048 rows, two-phase best) x 4096 columns, local SW on
+    an unrelated pair: the packed run and the int32 single-pass run report the same best cell and the same last row,
+    cell for cell -- a divergence anywhere in the 228 M rows above would show in that row -- and the oracle confirms
+    the cell on the window that ends at it."""
+    m, n = 228000000, 4096
+    s0, s1 = pkg.seqgen.unrelated_pair(m, n, cfg=63)
+    part = pkg.Partition(0, 0, m, n)
+    res = {}
+    for flags in (0, 2):
+        al = pkg.MI355Aligner(device=0, flags=flags)
+        try:
+            al.setSequences(s0, s1)
+            mg = pkg.Stage1Manager(part, keep_last_row=True)
+            al.alignPartition(part, mg)
+            st = al.getStatistics()
+            res[flags] = (tuple(mg.getBestScore()), mg.lastRow())
+            assert st["profile_kernel"] == (2 if flags == 0 else 1)
+        finally:
+            al.close()
+    assert res[0][0] == res[2][0]
+    assert np.array_equal(res[0][1], res[2][1])
+    i, j, score = res[0][0]
+    W = min(i, 600)
+    ref = oracle.stage1(s0[i - W:i], s1[:j], want_last_row=True)
+    assert ref["best"][2] == score and int(ref["last_row"][-1][0]) == score
+
+
 def test_match_last_column_follows_aligner_utils(pkg, oracle, aligner):
     """IAligner::matchLastColumn = AlignerUtils::matchColumn (M/libmasa/utils/AlignerUtils.cpp:50-107): first k with
     base.h + buffer.h == goal (aligned) or base.e + buffer.e + gap_open == goal (gapped); a sum above the goal is

@@ -17,7 +17,21 @@ al = pkg.MI355Aligner(device=0)
 areas = {}
 try:
     t = time.time(); r1 = stage1(al, s0, s1, work, sra_limit=limit, areas=areas); print("stage1 %.2f s best %s" % (time.time() - t, r1["best"]))
-    t = time.time(); r2 = stage2(al, s0, s1, work, sra_limit=limit, areas=areas); print("stage2 %.2f s, %d crosspoints" % (time.time() - t, len(r2["crosspoints"])))
+    acc2 = {"kernel_ms": 0.0, "calls": 0, "rows": 0, "cols": 0, "total_ms": 0.0}
+    orig2 = al.alignPartition
+    def counted2(part, mgr):
+        orig2(part, mgr)
+        st = al.getStatistics()
+        acc2["kernel_ms"] += st["kernel_ms"]; acc2["total_ms"] += st["total_ms"]; acc2["calls"] += 1
+        acc2["rows"] += part.i1 - part.i0; acc2["cols"] += part.j1 - part.j0
+    al.alignPartition = counted2
+    pr2 = cProfile.Profile()
+    t = time.time(); pr2.enable(); r2 = stage2(al, s0, s1, work, sra_limit=limit, areas=areas); pr2.disable()
+    print("stage2 %.2f s, %d crosspoints" % (time.time() - t, len(r2["crosspoints"])))
+    print("stage2 engine: %d calls, kernel %.1f ms (%.2f per call), wall in the engine %.1f ms, mean partition %d x %d" % (
+        acc2["calls"], acc2["kernel_ms"], acc2["kernel_ms"] / max(1, acc2["calls"]), acc2["total_ms"], acc2["rows"] // max(1, acc2["calls"]), acc2["cols"] // max(1, acc2["calls"])))
+    out2 = io.StringIO(); pstats.Stats(pr2, stream=out2).sort_stats("tottime").print_stats(12); print(out2.getvalue()[:2600])
+    al.alignPartition = orig2
     acc = {"kernel_ms": 0.0, "calls": 0, "cells": 0, "rows": 0, "cols": 0, "launches": 0}
     orig = al.alignPartition
     def counted(part, mgr):
