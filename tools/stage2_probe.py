@@ -1,6 +1,6 @@
 """Stage-2-shaped call (M/stage2/sw_stage2.cpp:387-441): a TALL, NARROW NW partition whose first column and first
 row are custom data, whose last column is dispatched progressively and whose manager says stop (mustContinue = 0)
-once the goal was seen in the first rows.  python tools/stage2_probe.py m n stop_after_rows"""
+once the goal was seen in the first rows.  python tools/stage2_probe.py m n stop_after_rows [special row interval] [rows per lane]"""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -24,7 +24,7 @@ class Mgr(Stage1Manager):
         if self.last_column_pos >= stop_rows:
             self.active = False
 
-al = pkg.MI355Aligner(device=0)
+al = pkg.MI355Aligner(device=0, rows_per_lane=int(sys.argv[5]) if len(sys.argv) > 5 else 0)
 al.setSequences(s0, s1)
 part = pkg.Partition(0, 0, m, n)
 for rep in range(3):
