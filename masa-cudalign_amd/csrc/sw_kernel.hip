@@ -380,9 +380,10 @@ sw_strip_kernel(const KernelArgs* __restrict__ ap) {
         const int s = __builtin_amdgcn_readfirstlane(claim_strip_common(ap, lane, 64 * R));
         if (s >= num_strips) break;
         if (poll_agent(a->abort_flag) != 0 || (a->host_abort != nullptr && poll_sys(a->host_abort) != 0)) {
-            // publish completion so that followers do not spin forever
+            // stopped: this wavefront is done (every strip still in flight holds an earlier ticket; see sw_kernel_pk16.inc)
             if (lane == 0) st_agent(&a->progress[s + 1], a->n);
             __builtin_amdgcn_wave_barrier();
+            break;
         } else {
             process_strip<R, SW, PROFILE, TRACK>(ap, s, lds, lane);
         }
