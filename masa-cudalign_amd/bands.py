@@ -211,7 +211,8 @@ class BandRunner:
 
     def run(self, m, j0, j1, recurrence=SMITH_WATERMAN, track_best=True, first_row_init_type=INIT_WITH_ZEROES,
             first_col_init_type=INIT_WITH_ZEROES, poll_sleep=0.0005, want_last_row=False, before_end=None,
-            force_int32=False, digest_inbound=False, special_row_interval=0, special_row_sink=None, n_total=None):
+            force_int32=False, digest_inbound=False, special_row_interval=0, special_row_sink=None, n_total=None,
+            keep_inbound=False):
         """seq1 of the engine must already hold the whole horizontal sequence (or at least [j0,j1)).
         digest_inbound: leave the crc32 of the boundary column this band received in self.inbound_crc (host transport:
         the segments as they arrive; p2p: the port's memory, read back once the band is through).
@@ -220,12 +221,15 @@ class BandRunner:
         gets each row as soon as its strip is complete -- cells = (H,F) of columns j0..j1-1, first_cell = the boundary
         column's cell of that row with f = -INF (AbstractDiagonalAligner.cpp:290-298).
         n_total: width of the whole matrix (default j1 of the last band = this band's j1): block pruning bounds what an
-        alignment can still gain by the rows and columns left in the SUPER-partition (M3)."""
+        alignment can still gain by the rows and columns left in the SUPER-partition (M3).
+        keep_inbound: leave the whole boundary column this band received, corner cell first, in self.inbound_column
+        ((m+1, 2) cells (H,E)) -- what the reference tees into C00000000.INIT_WITH_CUSTOM_DATA (sw_stage1.cpp:186-191)."""
         import zlib
         from .engine import AlignerError
         self.inbound_crc = 0 if digest_inbound else None
         eng, dist = self.engine, self.dist
         first, last = self.rank == 0, self.rank == self.world - 1
+        self.inbound_column = np.empty((m + 1, 2), dtype=np.int32) if (keep_inbound and not first) else None
         p2p = self.transport == "p2p"
         part = Partition(0, j0, m, j1)
         seg = self.segment_rows
@@ -253,6 +257,8 @@ class BandRunner:
                 corner[0, 0] = -2 * j0 - open_ if j0 > 0 else 0
             kw.update(first_column_init_type=INIT_WITH_CUSTOM_DATA, first_column=corner,
                       stream_first_column=not p2p, first_column_port=p2p)
+            if self.inbound_column is not None:
+                self.inbound_column[0] = corner[0]
         if p2p:
             self._exchange_ports(m)
         # Ordered start: band g+1 launches its kernel only after band g has launched its own.  It could do nothing
@@ -283,6 +289,8 @@ class BandRunner:
                     dist.recv(buf, src=self.rank - 1)
                     if digest_inbound:
                         self.inbound_crc = zlib.crc32(buf.numpy().tobytes(), self.inbound_crc)
+                    if self.inbound_column is not None:
+                        self.inbound_column[r0 + 1:r0 + ln + 1] = buf.numpy()
                     if inbound_h is not None:          # H of the boundary column at every possible special row
                         q0 = r0 // 256 + 1
                         q1 = (r0 + ln) // 256
@@ -462,6 +470,8 @@ class BandRunner:
                 flush_special(m)
         if digest_inbound and p2p and not first:
             self.inbound_crc = zlib.crc32(np.ascontiguousarray(eng.portRead(0, m), dtype=np.int32).tobytes())
+        if self.inbound_column is not None and p2p:
+            self.inbound_column[1:] = eng.portRead(0, m)
         if before_end is not None:       # e.g. read this band's slice of the last row while the stream is open
             before_end(eng)
         bx_stop.set()                   # the exchange thread keeps answering the other bands until every band is through
@@ -499,3 +509,58 @@ class BandRunner:
         out = [torch.empty_like(t) for _ in range(self.world)]
         self.dist.all_gather(out, t)
         return canonical_best([tuple(int(x) for x in o.tolist()) for o in out])
+
+
+def band_stage1(runner, m, j0, j1, work, sra_limit, n_total=None, recurrence=SMITH_WATERMAN,
+                first_row_init_type=INIT_WITH_ZEROES, first_col_init_type=INIT_WITH_ZEROES, **run_kw):
+    """Stage 1 of one band with its Special Rows Area: what a forked MASA-Core node leaves in its own work directory
+    (`work`/FORK.NN, Job::initializeWorkPath, M/common/Job.cpp:118-128) -- partition directory
+    `00000000.<j0>.<m>.<j1>` in absolute coordinates, one file per special row with (j1-j0+1) cells whose leading cell
+    is the boundary column's, the last row as the completion marker, the border markers (row marker at offset j0), and
+    for every band but the first the boundary column it received as `C00000000.INIT_WITH_CUSTOM_DATA` (the tee of
+    sw_stage1.cpp:186-191), so that stage 2 can walk back through this band and hand over to the band on its left at
+    that column.  The spacing of the rows follows `sra_limit` (the node's --disk-size) and the size of the WHOLE
+    matrix, m x n_total -- a split is a trim, and Job.cpp:62-67 computes the interval from the untrimmed sizes --
+    rounded up to the engine's strip height.
+    Collective: every rank of the chain calls it.  Returns {"best": the chain's best (i, j, score) in 1-based DP
+    coordinates as stage1.py's, "band_best": this band's own, as the engine reports it (0-based cell), "work":
+    this band's work directory, "special_rows": DP rows written}; `crosspoints/crosspoint_01.00` of every band holds
+    the chain's best (the reference: the running best relayed along the chain, sw_stage1.cpp:421-464 -- the last
+    node's file is the one that counts there)."""
+    from . import sra as sra_mod
+    first = runner.rank == 0
+    bwork = os.path.join(work, "FORK.%02d" % runner.rank) if runner.world > 1 else work
+    os.makedirs(bwork, exist_ok=True)
+    interval = sra_mod.flush_interval(m, n_total if n_total is not None else j1, sra_limit) if sra_limit > 0 else 0
+    area = sra_mod.SpecialRowsArea(sra_mod.special_rows_path(bwork, 1, 0), disk_limit=max(sra_limit, 1))
+    part = area.create_partition(0, j0, m, j1)
+    part.set_border_markers(first_row_init_type, j0, first_col_init_type if first else INIT_WITH_CUSTOM_DATA, 0)
+
+    def sink(dp, c0, cells):
+        part.write(dp, np.concatenate([np.asarray(c0, dtype=np.int32).reshape(1, 2), cells]))
+
+    got = {}
+    prev_end = run_kw.pop("before_end", None)
+
+    def before_end(eng):
+        got["row"] = eng.streamReadLastRow()
+        if prev_end is not None:
+            prev_end(eng)
+    band_best = runner.run(m, j0, j1, recurrence=recurrence, first_row_init_type=first_row_init_type,
+                           first_col_init_type=first_col_init_type, special_row_interval=interval,
+                           special_row_sink=sink if interval > 0 else None, n_total=n_total, want_last_row=True,
+                           before_end=before_end, keep_inbound=not first, **run_kw)
+    if first:
+        lead = 0 if first_col_init_type == INIT_WITH_ZEROES else -2 * m - (3 if first_col_init_type == 1 else 0)
+    else:
+        lead = int(runner.inbound_column[m, 0])
+        runner.inbound_column.tofile(os.path.join(part.path, "C00000000.INIT_WITH_CUSTOM_DATA"))
+    if m not in runner.special_rows:              # the partition's last row: sw_stage1.cpp:203-240's completion marker
+        part.write(m, np.concatenate([np.array([[lead, -INF]], dtype=np.int32), got["row"]]))
+    part.close()
+    best = runner.reduce_best(band_best)
+    if best[0] >= 0 or best[1] >= 0:
+        best = (best[0] + 1, best[1] + 1, best[2])       # the engine reports the 0-based cell, the files DP coordinates
+        sra_mod.write_crosspoint(sra_mod.crosspoint_path(bwork, 1, 0), best)
+    return {"best": tuple(best), "band_best": tuple(band_best), "work": bwork,
+            "special_rows": list(runner.special_rows) + ([m] if m not in runner.special_rows else [])}

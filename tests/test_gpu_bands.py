@@ -291,3 +291,40 @@ def test_running_best_travels_through_the_ports_in_both_directions(pkg, oracle):
     print("pruned cells (band 0, band 1, band 0 again): alone %s shared %s" % (res[False], res[True]))
     assert res[True][1] > res[False][1]                  # down the chain
     assert res[True][2] > res[True][0]                   # up the chain
+
+
+def _worker_area(rank, world, port, m, n, transport, work, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    import __graft_entry__ as graft
+    pkg = graft.load_package()
+    from masa_cudalign_amd.bands import BandRunner, band_limits, band_stage1
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        s0, s1 = pkg.seqgen.related_pair(m, n, cfg=11)
+        lim = band_limits(n, [1] * world)
+        al = pkg.MI355Aligner(device=0, rows_per_lane=4)          # 256-row strips: the block height of the reference run
+        al.setSequences(s0, s1)
+        runner = BandRunner(al, dist=dist, rank=rank, world=world, device=None, segment_rows=512, transport=transport)
+        res = band_stage1(runner, m, lim[rank], lim[rank + 1], work, 500 * 1024, n_total=n)
+        res["restarts"] = runner.restarts
+        dist.barrier()
+        al.close()
+        q.put((rank, res))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("transport", ["p2p", "host"])
+def test_band_stage1_leaves_the_area_of_a_forked_node(pkg, oracle, transport, tmp_path):
+    """The ENGINE's bands against MASA-Core run as --split=3 --part=1..3 (oracle/_ref/ref_driver, prebuilt): each
+    band's Special Rows Area -- rows with their boundary cell, last row, markers, the received boundary column --
+    is the forked node's, byte for byte; through the column ports and through the host."""
+    from test_bands_gloo import check_area_against_split_reference
+    # (the engine keeps AbstractDiagonalAligner's minimum spacing of 8192 rows, the serial block aligner of the reference
+    #  run has none: the budget is chosen so that the spacing is 33 strips of 256 rows for both)
+    rows = check_area_against_split_reference(pkg, oracle, tmp_path, 40000, 13200, 3, _worker_area, transport, sra_limit="500K")
+    assert rows >= 12
