@@ -1,0 +1,122 @@
+"""GPU (-m gpu): the packed kernel's HOT chunk loop (csrc/sw_kernel_pk16.inc, "the chunk loop") and every way out of it.
+A strip enters the hot loop after its 257th chunk (columns >= 16 448), so these cases are WIDE: the alignment's ridge,
+runs of N, a re-basing window and the end of the row all lie beyond that column, where a chunk of the hot instance has
+to hand over to the general one mid-way (exact replay, new maximum / window shift) or must not be taken by it at all
+(codes outside the table, the last chunks).  Bit-exact against the oracle, and against the int32 kernels (which have
+no such loop) at sizes the oracle cannot sweep."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+EDGE = {0: "AT_ANYWHERE", 1: "AT_SEQUENCE_1", 2: "AT_SEQUENCE_2", 3: "AT_SEQUENCE_1_OR_2", 4: "AT_SEQUENCE_1_AND_2"}
+ACGT = np.frombuffer(b"ACGT", dtype=np.uint8)
+
+
+def _wide_pair(kind, m, n, seed):
+    """seq1: n random letters; seq0: m letters related to seq1[j0 : j0 + m] (4 % substitutions, a few indels) with j0 far
+    beyond column 16 448, or unrelated"""
+    rng = np.random.default_rng(seed)
+    s1 = ACGT[rng.integers(0, 4, size=n)]
+    if kind == "unrelated":
+        return ACGT[rng.integers(0, 4, size=m)], s1
+    j0 = 20000 + int(rng.integers(0, 3000))
+    src = s1[j0:j0 + m + 200].copy()
+    out = []
+    i = 0
+    while len(out) < m and i < len(src):
+        r = rng.random()
+        if r < 0.04:
+            out.append(ACGT[rng.integers(0, 4)])
+            i += 1
+        elif r < 0.045:
+            i += int(rng.integers(1, 6))                       # deletion
+        elif r < 0.05:
+            out.extend(ACGT[rng.integers(0, 4, size=int(rng.integers(1, 6)))])   # insertion
+        else:
+            out.append(src[i])
+            i += 1
+    s0 = np.array(out[:m], dtype=np.uint8)
+    if len(s0) < m:
+        s0 = np.concatenate([s0, ACGT[rng.integers(0, 4, size=m - len(s0))]])
+    if kind == "with_n":                                        # codes outside the 4-letter table, inside the hot zone
+        for p in (17000, 21011, 21012, 21013, 30000, n - 300):
+            s1[p:p + int(rng.integers(1, 90))] = ord("N")
+        s0[m // 2:m // 2 + 3] = ord("N")
+    return np.ascontiguousarray(s0), np.ascontiguousarray(s1)
+
+
+@pytest.mark.parametrize("R", [0, 4, 12, 24, 32])
+@pytest.mark.parametrize("kind,start,end", [("related", 0, 0), ("unrelated", 0, 0), ("with_n", 0, 0), ("related", 4, 4),
+                                            ("related", 1, 3), ("related", 2, 2)])
+def test_wide_partitions_against_the_oracle(pkg, oracle, kind, start, end, R):
+    from helpers import oracle_kwargs
+    m, n = (2600, 40000) if R in (0, 32) else (1700, 36000)
+    s0, s1 = _wide_pair(kind, m, n, seed=1000 + 7 * R + start)
+    al = pkg.MI355Aligner(device=0, rows_per_lane=R)
+    try:
+        al.setSequences(s0, s1)
+        part = pkg.Partition(0, 0, m, n)
+        mg = pkg.Stage1Manager(part, alignment_start=getattr(pkg, EDGE[start]), alignment_end=getattr(pkg, EDGE[end]),
+                               keep_last_row=True, keep_last_column=True)
+        al.alignPartition(part, mg)
+        st = al.getStatistics()
+        assert st["profile_kernel"] == 2                       # the packed family ran, no fallback
+        kw = oracle_kwargs(oracle, dict(start=start, end=end, pruning=False, disk=-1, block=(st["strip_rows"], 1 << 20)), m, n)
+        kw.update(want_last_row=True, want_last_col=True)
+        ref = oracle.stage1(s0, s1, **kw)
+        assert tuple(mg.getBestScore()) == tuple(ref["best"])
+        assert np.array_equal(mg.lastRow(), ref["last_row"])
+        assert np.array_equal(mg.lastColumn(), ref["last_col"])
+        if kind != "unrelated" and start == 0:
+            assert ref["best"][1] > 16448 + 64                  # the ridge does lie where the hot loop runs
+    finally:
+        al.close()
+
+
+@pytest.mark.parametrize("prune", [False, True])
+def test_hot_loop_and_int32_kernels_agree_on_a_large_related_pair(pkg, prune):
+    """300 000 x 200 000 related pair (score ~ 170 000: several window shifts, a ridge of 200 000 columns in exact mode,
+    with pruning about a third of the slabs skipped): the packed kernels with their hot loop and the int32 kernels give
+    the same best cell; unpruned also the same last row and last column, cell for cell."""
+    m, n = 300000, 200000
+    s0, s1 = pkg.seqgen.related_pair(m, n, cfg=71)
+    part = pkg.Partition(0, 0, m, n)
+    res = {}
+    for flags in (0, 2):
+        al = pkg.MI355Aligner(device=0, flags=flags)
+        try:
+            al.setSequences(s0, s1)
+            mg = pkg.Stage1Manager(part, keep_last_row=True, keep_last_column=True, block_pruning=prune and flags == 0)
+            al.alignPartition(part, mg)
+            st = al.getStatistics()
+            assert st["profile_kernel"] == (2 if flags == 0 else 1)
+            res[flags] = (tuple(mg.getBestScore()), mg.lastRow(), mg.lastColumn(), st["pruned_cells"])
+        finally:
+            al.close()
+    assert res[0][0] == res[2][0] and res[0][0][2] > 100000
+    if prune:
+        assert res[0][3] > 0.2 * m * n
+        assert np.all(res[0][1][:, 0] <= res[2][1][:, 0])       # a pruned row is a lower bound of the unpruned one
+    else:
+        assert np.array_equal(res[0][1], res[2][1])
+        assert np.array_equal(res[0][2], res[2][2])
+
+
+def test_score_only_pass_with_mixed_heights_agrees_with_int32(pkg):
+    """the C2 kernel itself (mixed strip heights in one launch, score only, hot loop in every strip) on a shape that
+    engages it -- 2.2 rounds of 1536-row strips -- against the int32 kernels: same best cell"""
+    m, n = 3400000, 70000
+    s0, s1 = pkg.seqgen.related_pair(m, n, cfg=72)
+    part = pkg.Partition(0, 0, m, n)
+    res = {}
+    for flags in (0, 2):
+        al = pkg.MI355Aligner(device=0, flags=flags)
+        try:
+            al.setSequences(s0, s1)
+            mg = pkg.Stage1Manager(part)
+            al.alignPartition(part, mg)
+            res[flags] = (tuple(mg.getBestScore()), al.getStatistics())
+        finally:
+            al.close()
+    assert res[0][0] == res[2][0]
+    assert res[0][1]["profile_kernel"] == 2

@@ -1,4 +1,4 @@
-"""Block pruning on/off on a related pair: python tools/prune_probe.py m n"""
+"""Block pruning on/off on a related pair: python tools/prune_probe.py m n [rows per lane [passes, e.g. 1 = one pruned pass, 01 = unpruned then pruned]]"""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as g
@@ -9,7 +9,7 @@ s0, s1 = pkg.seqgen.related_pair(m, n, cfg=5)
 al = pkg.MI355Aligner(device=0, rows_per_lane=R)
 al.setSequences(s0, s1)
 part = pkg.Partition(0, 0, m, n)
-for prune in (False, True, True):
+for prune in ([c == '1' for c in sys.argv[4]] if len(sys.argv) > 4 else (False, True, True)):
     al.streamBegin(part, prune_blocks=prune)
     while True:
         rows, fin = al.streamPoll()
