@@ -41,7 +41,9 @@ def main():
     res = {"workload": "%dx%d related pair (seqgen cfg=%d), local, stages 1-6 natively" % (m, n, cfg), "sra_bytes": limit,
            "best": list(out["best"]), "seconds": {str(k): v for k, v in out["seconds"].items()}, "total_seconds": total,
            "crosspoints": {str(k): v for k, v in out["crosspoints"].items()},
-           "stage1_gcups": out["stage1"]["gcups"], "stage3_rounds": out.get("stage3", {}).get("rounds"),
+           "stage1_gcups": out["stage1"]["gcups"], "stage1_kernel_ms": out["stage1"].get("kernel_ms"),
+           "stage1_strip_rows": out["stage1"].get("strip_rows"), "stage1_pruned_fraction": out["stage1"].get("pruned_cells", 0) / float(m) / n,
+           "stage3_rounds": out.get("stage3", {}).get("rounds"),
            "stage4": out.get("stage4"), "alignment_score": out["alignment"].raw_score if out["alignment"] else None,
            "text_bytes": len(out["text"]) if out["text"] else 0}
     if float(m) * n <= 4e9:
