@@ -75,31 +75,43 @@ def test_wide_partitions_against_the_oracle(pkg, oracle, kind, start, end, R):
 
 @pytest.mark.parametrize("prune", [False, True])
 def test_hot_loop_and_int32_kernels_agree_on_a_large_related_pair(pkg, prune):
-    """300 000 x 200 000 related pair (score ~ 170 000: several window shifts, a ridge of 200 000 columns in exact mode,
-    with pruning about a third of the slabs skipped): the packed kernels with their hot loop and the int32 kernels give
-    the same best cell; unpruned also the same last row and last column, cell for cell."""
+    """300 000 x 200 000 related pair (score ~ 170 000: several window shifts, a ridge of 200 000 columns in exact mode;
+    with pruning about a third of the slabs skipped, most of them in runs that are tested and written out eight at a
+    time): the packed kernels with their hot loop and the int32 kernels give the same best cell; unpruned also the same
+    special rows, last row and last column, cell for cell; pruned, every row is a lower bound of the unpruned one, with
+    the same maximum where the alignment crosses it."""
     m, n = 300000, 200000
     s0, s1 = pkg.seqgen.related_pair(m, n, cfg=71)
     part = pkg.Partition(0, 0, m, n)
     res = {}
     for flags in (0, 2):
-        al = pkg.MI355Aligner(device=0, flags=flags)
+        al = pkg.MI355Aligner(device=0, flags=flags, rows_per_lane=16)
         try:
             al.setSequences(s0, s1)
-            mg = pkg.Stage1Manager(part, keep_last_row=True, keep_last_column=True, block_pruning=prune and flags == 0)
+            mg = pkg.Stage1Manager(part, keep_last_row=True, keep_last_column=True, block_pruning=prune and flags == 0,
+                                   special_row_interval=65536)
             al.alignPartition(part, mg)
             st = al.getStatistics()
             assert st["profile_kernel"] == (2 if flags == 0 else 1)
-            res[flags] = (tuple(mg.getBestScore()), mg.lastRow(), mg.lastColumn(), st["pruned_cells"])
+            rows = {i: mg.specialRow(i) for i in sorted(mg.special_rows)}
+            res[flags] = (tuple(mg.getBestScore()), mg.lastRow(), mg.lastColumn(), st["pruned_cells"], rows)
         finally:
             al.close()
     assert res[0][0] == res[2][0] and res[0][0][2] > 100000
+    assert sorted(res[0][4]) == sorted(res[2][4]) and len(res[0][4]) >= 4
     if prune:
         assert res[0][3] > 0.2 * m * n
         assert np.all(res[0][1][:, 0] <= res[2][1][:, 0])       # a pruned row is a lower bound of the unpruned one
+        for i in res[0][4]:
+            a, b = res[0][4][i][:, 0], res[2][4][i][:, 0]
+            assert np.all(a <= b), i
+            if i <= res[2][0][0]:                               # the alignment's ridge crosses this row: its cell survives
+                assert a.max() == b.max(), i
     else:
         assert np.array_equal(res[0][1], res[2][1])
         assert np.array_equal(res[0][2], res[2][2])
+        for i in res[0][4]:
+            assert np.array_equal(res[0][4][i], res[2][4][i]), i
 
 
 def test_score_only_pass_with_mixed_heights_agrees_with_int32(pkg):

@@ -5,7 +5,7 @@ import __graft_entry__ as g
 pkg = g.load_package()
 m, n = int(sys.argv[1]), int(sys.argv[2])
 R = int(sys.argv[3]) if len(sys.argv) > 3 else 0
-s0, s1 = pkg.seqgen.related_pair(m, n, cfg=5)
+s0, s1 = (pkg.seqgen.unrelated_pair if os.environ.get('PROBE_UNRELATED') else pkg.seqgen.related_pair)(m, n, cfg=5)
 al = pkg.MI355Aligner(device=0, rows_per_lane=R)
 al.setSequences(s0, s1)
 part = pkg.Partition(0, 0, m, n)
