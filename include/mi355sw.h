@@ -323,6 +323,18 @@ int mi355sw_stage5(const char* seq0, int32_t seq0_len, const char* seq1, int32_t
                    int32_t count, int32_t** gaps0, int64_t* n_gaps0, int32_t** gaps1, int64_t* n_gaps1,
                    mi355sw_stage5_totals* totals, int32_t* failed_at);
 
+/* ---- stage 6: the text of alignment.NN.txt from the first block on -------------------------------------------------
+ * Replaces printText of M/stage6/sw_stage6.cpp:60-262 after its three header lines (which the caller writes: they need the
+ * sequences' descriptions and trim positions): blocks of 60 columns -- "Query:" line, match marks with the block's and the
+ * running score, "Sbjct:" line -- and the summary.  seq0 / seq1 = the FORWARD data of the whole sequences
+ * (Sequence::getForwardData()), (i0, j0) -> (i1, j1) = Alignment start / end (absolute 1-based positions; all four -1: "no
+ * alignment produced"), gaps0 / gaps1 = the alignment's gap lists as (position, length) pairs in Alignment::finalize's
+ * order.  `*text` (release it with mi355sw_free) is not NUL-counted in *text_len.  MI355SW_ETRACEBACK: the text re-scores
+ * to something else than raw_score ("Stage6 error: Alignment score is different", :243-247); totals are filled either way. */
+int mi355sw_stage6_text(const char* seq0, int32_t seq0_len, const char* seq1, int32_t seq1_len, int32_t i0, int32_t j0,
+                        int32_t i1, int32_t j1, const int32_t* gaps0, int32_t n_gaps0, const int32_t* gaps1, int32_t n_gaps1,
+                        int64_t raw_score, char** text, int64_t* text_len, mi355sw_stage5_totals* totals);
+
 /* device enumeration: X/cuda_util.cpp:191-287 (--list-gpus, GPU weights) */
 int mi355sw_device_count(void);
 int mi355sw_device_info(int32_t device, char* name, size_t name_len, int32_t* compute_units, int32_t* clock_mhz, int64_t* hbm_bytes);

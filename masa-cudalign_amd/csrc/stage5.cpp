@@ -130,3 +130,126 @@ extern "C" int mi355sw_stage5(const char* seq0, int32_t len0, const char* seq1, 
     *totals = o.tot;
     return MI355SW_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Stage 6 on the host: the body of alignment.NN.txt -- 60-column blocks of Query / match marks / Sbjct with positions and
+// running scores, then the summary -- from the forward sequence data and the alignment's two gap lists.  Replaces
+// printText of M/stage6/sw_stage6.cpp:60-262 from the first block on (the caller writes the three header lines, which
+// need the sequences' descriptions and trim positions).  Plain host code like the reference's; 200 MB of text for a
+// 46 M-column alignment is a second here.
+#include <cstdio>
+#include <string>
+
+namespace stage6 {
+
+enum { COLS = 60 };      // (the scores are stage 5's, above)
+
+// one sequence's side of a block (:96-132 / :134-170): walks from *pos towards `last` in direction `dir`, emitting a
+// '-' wherever the gap list says so (an entry (p, len) sits before position p walking forwards, after it backwards)
+struct Walker {
+    const unsigned char* d;
+    const int32_t* gaps;     // (position, length) pairs
+    int n_gaps, dir, pos, last, cur, left_pos, left_len;
+    bool done;
+    void load() {
+        if (cur >= 0 && cur < n_gaps) { left_pos = gaps[2 * cur]; left_len = gaps[2 * cur + 1]; }
+        else { left_pos = -1; left_len = -1; }
+    }
+    int fill(unsigned char* out) {
+        int k = 0, len = 0;
+        while (k < COLS && !done) {
+            if (left_pos == pos + (dir > 0 ? 0 : 1)) {
+                out[len++] = '-';
+                if (--left_len == 0) { cur += dir; load(); }
+            } else {
+                out[len++] = d[pos - 1];
+                if (pos == last) { done = true; break; }
+                pos += dir;
+            }
+            k++;
+        }
+        return len;
+    }
+};
+}  // namespace stage6
+
+extern "C" int mi355sw_stage6_text(const char* seq0, int32_t seq0_len, const char* seq1, int32_t seq1_len, int32_t i0, int32_t j0,
+                                   int32_t i1, int32_t j1, const int32_t* gaps0, int32_t n_gaps0, const int32_t* gaps1,
+                                   int32_t n_gaps1, int64_t raw_score, char** text, int64_t* text_len,
+                                   mi355sw_stage5_totals* totals) {
+    if (!seq0 || !seq1 || !text || !text_len || (n_gaps0 > 0 && !gaps0) || (n_gaps1 > 0 && !gaps1)) return MI355SW_EINVAL;
+    *text = nullptr; *text_len = 0;
+    const bool none = (i0 == -1 && j0 == -1 && i1 == -1 && j1 == -1);
+    if (!none && (i0 < 1 || i0 > seq0_len || i1 < 1 || i1 > seq0_len || j0 < 1 || j0 > seq1_len || j1 < 1 || j1 > seq1_len))
+        return MI355SW_EINVAL;
+    stage6::Walker q = {(const unsigned char*) seq0, gaps0, n_gaps0, i1 > i0 ? 1 : -1, i0, i1, 0, -1, -1, none};
+    stage6::Walker s = {(const unsigned char*) seq1, gaps1, n_gaps1, j1 > j0 ? 1 : -1, j0, j1, 0, -1, -1, none};
+    q.cur = q.dir > 0 ? 0 : n_gaps0 - 1;
+    s.cur = s.dir > 0 ? 0 : n_gaps1 - 1;
+    q.load(); s.load();
+    std::string out;
+    out.reserve((size_t) (none ? 256 : ((long long) (abs(i1 - i0) + abs(j1 - j0)) / 60 + 2) * 230));
+    long long score = 0, gap_openings = 0, gap_extentions = 0, matches = 0, mismatches = 0;
+    int qgap = 0, sgap = 0;
+    if (none) out += "There was no alignment produced!\n\n";
+    using namespace stage6;
+    unsigned char qb[COLS + 1], sb[COLS + 1], marks[COLS + 1];
+    char line[64];
+    while (!q.done || !s.done) {
+        const int qp = q.pos, sp = s.pos;
+        int ql = q.fill(qb), sl = s.fill(sb);
+        while (sl < ql) sb[sl++] = '-';
+        while (ql < sl) qb[ql++] = '-';
+        snprintf(line, sizeof line, "Query: %8d ", qp);
+        out += line;
+        out.append((const char*) qb, ql);
+        snprintf(line, sizeof line, " %8d\n", q.pos);
+        out += line;
+        out += "                ";
+        long long temp = 0;
+        for (int k = 0; k < ql; k++) {
+            const unsigned char a = qb[k], b = sb[k];
+            marks[k] = (a == b) ? '|' : ' ';
+            if (a == '-') {
+                if (qgap) temp += -GAP_EXT; else { temp += -GAP_OPEN - GAP_EXT; gap_openings++; }
+                gap_extentions++;
+                qgap = 1; sgap = 0;
+            } else if (b == '-') {
+                if (sgap) temp += -GAP_EXT; else { temp += -GAP_OPEN - GAP_EXT; gap_openings++; }
+                gap_extentions++;
+                qgap = 0; sgap = 1;
+            } else {
+                if (a == b) { temp += MATCH; matches++; } else { temp += MISMATCH; mismatches++; }
+                qgap = sgap = 0;
+            }
+        }
+        score += temp;
+        out.append((const char*) marks, ql);
+        snprintf(line, sizeof line, " [%lld/%lld]\n", temp, score);
+        out += line;
+        snprintf(line, sizeof line, "Sbjct: %8d ", sp);
+        out += line;
+        out.append((const char*) sb, sl);
+        snprintf(line, sizeof line, " %8d\n", s.pos);
+        out += line;
+        out += "\n\n";
+    }
+    if (totals) {
+        totals->score = score; totals->matches = matches; totals->mismatches = mismatches;
+        totals->gap_open = gap_openings; totals->gap_extensions = gap_extentions;
+    }
+    if (score != raw_score) return MI355SW_ETRACEBACK;      // "Stage6 error: Alignment score is different" (:243-247)
+    out += "Summary:\n\n";
+    snprintf(line, sizeof line, "Total Score:    %10lld\n", score); out += line;
+    snprintf(line, sizeof line, "Matches:        %10lld (+%d)\n", matches, MATCH); out += line;
+    snprintf(line, sizeof line, "Mismatches:     %10lld (%d)\n", mismatches, MISMATCH); out += line;
+    snprintf(line, sizeof line, "Gap Openings:   %10lld (%d)\n", gap_openings, -GAP_OPEN); out += line;
+    snprintf(line, sizeof line, "Gap Extentions: %10lld (%d)\n", gap_extentions, -GAP_EXT); out += line;
+    char* buf = (char*) malloc(out.size() + 1);
+    if (!buf) return MI355SW_ENOMEM;
+    memcpy(buf, out.data(), out.size());
+    buf[out.size()] = 0;
+    *text = buf;
+    *text_len = (int64_t) out.size();
+    return MI355SW_OK;
+}

@@ -150,7 +150,7 @@ ABI_SYMBOLS = [
     "mi355sw_stream_abort", "mi355sw_stream_end", "mi355sw_stream_strip_scores",
     "mi355sw_stream_best_hint", "mi355sw_stream_running_best",
     "mi355sw_port_create", "mi355sw_port_open", "mi355sw_port_attach", "mi355sw_port_reset", "mi355sw_port_rows_ready", "mi355sw_port_read",
-    "mi355sw_port_local_pointers", "mi355sw_port_close", "mi355sw_stage4", "mi355sw_free", "mi355sw_stage5",
+    "mi355sw_port_local_pointers", "mi355sw_port_close", "mi355sw_stage4", "mi355sw_free", "mi355sw_stage5", "mi355sw_stage6_text",
     "mi355sw_device_count", "mi355sw_device_info",
 ]
 
@@ -237,6 +237,9 @@ def load_library():
     lib.mi355sw_stage5.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32,
                                    C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(C.c_void_p), C.POINTER(C.c_int64),
                                    C.POINTER(Stage5Totals), C.POINTER(C.c_int32)]
+    lib.mi355sw_stage6_text.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                        C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int64, C.POINTER(C.c_void_p),
+                                        C.POINTER(C.c_int64), C.POINTER(Stage5Totals)]
     lib.mi355sw_device_info.argtypes = [C.c_int32, C.c_char_p, C.c_size_t, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                         C.POINTER(C.c_int64)]
     _lib = lib
@@ -264,6 +267,25 @@ def stage5_events(data0, data1, crosspoints):
         lib.mi355sw_free(g0)
         lib.mi355sw_free(g1)
     return a0, a1, {k: int(getattr(tot, k)) for k, _ in Stage5Totals._fields_}
+
+
+def stage6_body(forward0, forward1, start, end, gaps0, gaps1, raw_score):
+    """mi355sw_stage6_text (host code, no GPU): the bytes of alignment.NN.txt after its three header lines."""
+    lib = load_library()
+    d0, d1 = _as_u8(forward0), _as_u8(forward1)
+    g0 = np.ascontiguousarray(gaps0, dtype=np.int32).reshape(-1, 2)
+    g1 = np.ascontiguousarray(gaps1, dtype=np.int32).reshape(-1, 2)
+    text, n, tot = C.c_void_p(), C.c_int64(), Stage5Totals()
+    rc = lib.mi355sw_stage6_text(d0.ctypes.data, len(d0), d1.ctypes.data, len(d1), int(start[0]), int(start[1]), int(end[0]), int(end[1]),
+                                 g0.ctypes.data, len(g0), g1.ctypes.data, len(g1), int(raw_score), C.byref(text), C.byref(n), C.byref(tot))
+    if rc == -8:
+        raise RuntimeError("Stage6 error: Alignment score is different (%d != %d)" % (tot.score, raw_score))
+    if rc != 0:
+        raise AlignerError("stage6: %s" % ERRORS.get(rc, rc))
+    try:
+        return C.string_at(text.value, n.value)
+    finally:
+        lib.mi355sw_free(text)
 
 
 def _as_u8(seq):

@@ -93,102 +93,6 @@ def stage6_text(al, seq0, seq1):
     # (the reference compares SEQUENCE 0's size with sequence 1's length here, :76)
     out.append("(%d)\n" % len(seq1) if seq0.original_size == len(seq1) else "[%d..%d](%d)\n" % (seq1.offset0, seq1.offset1, len(seq1)))
     out.append("\n")
-    i0, j0, i1, j1 = al.start[0], al.start[1], al.end[0], al.end[1]
-    gaps0, gaps1 = [list(g) for g in al.gaps[0]], [list(g) for g in al.gaps[1]]
-    COLS = 60
-    dir_i = 1 if i1 > i0 else -1
-    dir_j = 1 if j1 > j0 else -1
-    c0 = 0 if dir_i > 0 else len(gaps0) - 1
-    c1 = 0 if dir_j > 0 else len(gaps1) - 1
-    end_gap = [-1, -1]
-    cur0 = list(gaps0[c0]) if 0 <= c0 < len(gaps0) else list(end_gap)
-    cur1 = list(gaps1[c1]) if 0 <= c1 < len(gaps1) else list(end_gap)
-    i, j = i0, j0
-    end_i = end_j = False
-    score = gap_openings = gap_extentions = matches = mismatches = 0
-    qgap = sgap = 0
-    if i0 == -1 and j0 == -1 and i1 == -1 and j1 == -1:
-        end_i = end_j = True
-        out.append("There was no alignment produced!\n\n")
-    while not end_i or not end_j:
-        query, qp = [], i
-        k = 0
-        while k < COLS and not end_i:
-            if cur0[0] == i + (0 if dir_i > 0 else 1):
-                query.append(45)
-                cur0[1] -= 1
-                if cur0[1] == 0:
-                    c0 += dir_i
-                    cur0 = list(gaps0[c0]) if 0 <= c0 < len(gaps0) else list(end_gap)
-            else:
-                query.append(int(d0[i - 1]))
-                if i == i1:
-                    end_i = True
-                    break
-                i += dir_i
-            k += 1
-        subject, sp = [], j
-        k = 0
-        while k < COLS and not end_j:
-            if cur1[0] == j + (0 if dir_j > 0 else 1):
-                subject.append(45)
-                cur1[1] -= 1
-                if cur1[1] == 0:
-                    c1 += dir_j
-                    cur1 = list(gaps1[c1]) if 0 <= c1 < len(gaps1) else list(end_gap)
-            else:
-                subject.append(int(d1[j - 1]))
-                if j == j1:
-                    end_j = True
-                    break
-                j += dir_j
-            k += 1
-        if len(subject) < len(query):
-            subject += [45] * (len(query) - len(subject))
-        else:
-            query += [45] * (len(subject) - len(query))
-        qs, ss = bytes(query).decode("latin-1"), bytes(subject).decode("latin-1")
-        out.append("Query: %8d %s %8d\n" % (qp, qs, i))
-        out.append("                ")
-        temp = 0
-        marks = []
-        for q, s in zip(query, subject):
-            marks.append("|" if q == s else " ")
-            if q == 45:
-                if qgap:
-                    temp += -GAP_EXT
-                else:
-                    temp += -GAP_OPEN - GAP_EXT
-                    gap_openings += 1
-                gap_extentions += 1
-                qgap, sgap = 1, 0
-            elif s == 45:
-                if sgap:
-                    temp += -GAP_EXT
-                else:
-                    temp += -GAP_OPEN - GAP_EXT
-                    gap_openings += 1
-                gap_extentions += 1
-                qgap, sgap = 0, 1
-            else:
-                if q == s:
-                    temp += MATCH
-                    matches += 1
-                else:
-                    temp += MISMATCH
-                    mismatches += 1
-                qgap = sgap = 0
-        score += temp
-        out.append("".join(marks))
-        out.append(" [%d/%d]\n" % (temp, score))
-        out.append("Sbjct: %8d %s %8d\n" % (sp, ss, j))
-        out.append("\n\n")
-    if score != al.raw_score:
-        raise RuntimeError("Stage6 error: Alignment score is different (%d != %d)" % (score, al.raw_score))
-    out.append("Summary:\n\n")
-    out.append("Total Score:    %10d\n" % score)
-    out.append("Matches:        %10d (+%d)\n" % (matches, MATCH))
-    out.append("Mismatches:     %10d (%d)\n" % (mismatches, MISMATCH))
-    out.append("Gap Openings:   %10d (%d)\n" % (gap_openings, -GAP_OPEN))
-    out.append("Gap Extentions: %10d (%d)\n" % (gap_extentions, -GAP_EXT))
-    return "".join(out).encode("latin-1")
+    # the blocks and the summary: csrc/stage6.cpp (mi355sw_stage6_text), host code like the reference's
+    from .engine import stage6_body
+    return "".join(out).encode("latin-1") + stage6_body(d0, d1, al.start, al.end, al.gaps[0], al.gaps[1], al.raw_score)
