@@ -501,8 +501,9 @@ class MI355Aligner:
         return buf[:cnt].copy()
 
     # -- stage 4 (Myers-Miller refinement of the stage-3 crosspoints, M/stage4/sw_stage4.cpp) ------------------
-    def stage4(self, crosspoints, max_partition_size=16):
-        """crosspoints: [(type, i, j, score), ...] as in crosspoint_03.NN; returns (refined list, stats dict)"""
+    def stage4(self, crosspoints, max_partition_size=16, as_array=False):
+        """crosspoints: [(type, i, j, score), ...] as in crosspoint_03.NN; returns (refined list, stats dict); as_array: the
+        list as an (N, 4) int32 array (millions of points at sizes like C3: tuples of Python ints cost seconds)"""
         cp = np.ascontiguousarray(crosspoints, dtype=np.int32).reshape(-1, 4)
         out, n, st = C.c_void_p(), C.c_int32(), Stage4Stats()
         self._check(self._lib.mi355sw_stage4(self._h, cp.ctypes.data, len(cp), max_partition_size, C.byref(out), C.byref(n),
@@ -510,7 +511,8 @@ class MI355Aligner:
         buf = (C.c_int32 * (n.value * 4)).from_address(out.value)
         res = np.frombuffer(buf, dtype=np.int32).reshape(n.value, 4).copy()
         self._lib.mi355sw_free(out)
-        return [tuple(int(x) for x in r) for r in res], {k: getattr(st, k) for k, _ in Stage4Stats._fields_}
+        stats = {k: getattr(st, k) for k, _ in Stage4Stats._fields_}
+        return (res if as_array else [tuple(r) for r in res.tolist()]), stats
 
     # -- column ports (boundary column GPU to GPU over xGMI) ----------------------------------------
     def portCreate(self, rows):

@@ -17,7 +17,7 @@ import numpy as np
 
 from .manager import AT_ANYWHERE
 from .engine import INF
-from .crosspoints import Crosspoint, CrosspointsFile, crosspoint_file
+from .crosspoints import Crosspoint, CrosspointsFile, crosspoint_file, save_array
 from .stage1 import stage1
 from .stage2 import stage2
 from .stage3 import stage3
@@ -95,12 +95,13 @@ def _traceback(aligner, seq0, seq1, d0, d1, work, ident, alignment_start, sra_li
     t = time.time()
     aligner.setSequences(d0, d1)
     try:
-        cp4, st4 = aligner.stage4(r3["crosspoints"], max_partition_size)
+        try:
+            cp4, st4 = aligner.stage4(r3["crosspoints"], max_partition_size, as_array=True)
+        except TypeError:              # an aligner double without the array form
+            cp4, st4 = aligner.stage4(r3["crosspoints"], max_partition_size)
     finally:
         aligner.unsetSequences()
-    f4 = CrosspointsFile(crosspoint_file(work, 4, ident))
-    f4.extend(Crosspoint(i, j, s, ty) for (ty, i, j, s) in cp4)
-    f4.save()
+    save_array(crosspoint_file(work, 4, ident), cp4)          # (millions of points at sizes like C3: no object per point)
     clock(4, t)
     t = time.time()
     al = stage56.stage5(seq0, seq1, cp4)
