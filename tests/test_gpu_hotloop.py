@@ -101,9 +101,10 @@ def test_hot_loop_and_int32_kernels_agree_on_a_large_related_pair(pkg, prune):
     assert sorted(res[0][4]) == sorted(res[2][4]) and len(res[0][4]) >= 4
     if prune:
         assert res[0][3] > 0.2 * m * n
-        assert np.all(res[0][1][:, 0] <= res[2][1][:, 0])       # a pruned row is a lower bound of the unpruned one
+        assert np.all(res[0][1] <= res[2][1])                   # a pruned row is a lower bound of the unpruned one, H and F
         for i in res[0][4]:
             a, b = res[0][4][i][:, 0], res[2][4][i][:, 0]
+            assert np.all(res[0][4][i] <= res[2][4][i]), i      # (a slab written out by nobody would show as stale cells here)
             assert np.all(a <= b), i
             if i <= res[2][0][0]:                               # the alignment's ridge crosses this row: its cell survives
                 assert a.max() == b.max(), i
@@ -112,6 +113,31 @@ def test_hot_loop_and_int32_kernels_agree_on_a_large_related_pair(pkg, prune):
         assert np.array_equal(res[0][2], res[2][2])
         for i in res[0][4]:
             assert np.array_equal(res[0][4][i], res[2][4][i]), i
+
+
+def test_two_phase_run_with_pruning_locates_the_same_cell(pkg, monkeypatch):
+    """value-only main pass (the kernels very tall partitions get) with pruning -- runs of pruned slabs also write the
+    checkpoint rows the exact pass restarts from -- then the exact pass: the same best cell as the int32 single pass"""
+    m, n = 300000, 200000
+    s0, s1 = pkg.seqgen.related_pair(m, n, cfg=71)
+    part = pkg.Partition(0, 0, m, n)
+    res = {}
+    for flags in (0, 2):
+        if flags == 0:
+            monkeypatch.setenv("MI355SW_TWO_PHASE", "1")
+        else:
+            monkeypatch.delenv("MI355SW_TWO_PHASE", raising=False)
+        al = pkg.MI355Aligner(device=0, flags=flags, rows_per_lane=8)
+        try:
+            al.setSequences(s0, s1)
+            mg = pkg.Stage1Manager(part, block_pruning=flags == 0)
+            al.alignPartition(part, mg)
+            st = al.getStatistics()
+            res[flags] = (tuple(mg.getBestScore()), st)
+        finally:
+            al.close()
+    assert res[0][1]["kernel_launches"] >= 2 and res[0][1]["pruned_cells"] > 0.2 * m * n
+    assert res[0][0] == res[2][0]
 
 
 def test_score_only_pass_with_mixed_heights_agrees_with_int32(pkg):
