@@ -46,6 +46,11 @@ def main():
            "stage3_rounds": out.get("stage3", {}).get("rounds"),
            "stage4": out.get("stage4"), "alignment_score": out["alignment"].raw_score if out["alignment"] else None,
            "text_bytes": len(out["text"]) if out["text"] else 0}
+    # the same digests tools/dropin_scale.py records for MASA-Core's own stages on the engine: equal = the same files
+    import hashlib
+    res["alignment_sha256"] = hashlib.sha256(out["text"]).hexdigest() if out["text"] else None
+    cp4 = os.path.join(work, "crosspoints", "crosspoint_04.00")
+    res["crosspoint_04_sha256"] = hashlib.sha256(open(cp4, "rb").read()).hexdigest() if os.path.exists(cp4) else None
     if float(m) * n <= 4e9:
         oracle = g.load_oracle()
         res["oracle_best"] = list(oracle.stage1(s0, s1)["best"])
