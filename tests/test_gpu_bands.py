@@ -328,3 +328,78 @@ def test_band_stage1_leaves_the_area_of_a_forked_node(pkg, oracle, transport, tm
     #  run has none: the budget is chosen so that the spacing is 33 strips of 256 rows for both)
     rows = check_area_against_split_reference(pkg, oracle, tmp_path, 40000, 13200, 3, _worker_area, transport, sra_limit="500K")
     assert rows >= 12
+
+
+def _worker_wide(rank, world, port, m, n, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    import __graft_entry__ as graft
+    pkg = graft.load_package()
+    from masa_cudalign_amd.bands import BandRunner, band_limits
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        s0, s1 = pkg.seqgen.related_pair(m, n, cfg=73)
+        lim = band_limits(n, [1] * world)
+        out = {}
+        for mode in ("plain", "pruned"):
+            al = pkg.MI355Aligner(device=0, rows_per_lane=16)
+            al.setSequences(s0, s1)
+            runner = BandRunner(al, dist=dist, rank=rank, world=world, device=None, segment_rows=8192, transport="p2p",
+                                prune_blocks=(mode == "pruned"))
+            rows = {}
+            best = runner.run(m, lim[rank], lim[rank + 1], special_row_interval=32768, n_total=n,
+                              special_row_sink=lambda dp, c0, cells: rows.__setitem__(dp, (c0.copy(), cells.copy())))
+            st = al.getStatistics()
+            out[mode] = dict(best=tuple(runner.reduce_best(best)), rows=rows, pruned=int(st["pruned_cells"]), cells=int(st["cells"]),
+                             restarts=runner.restarts, kernel=st["profile_kernel"])
+            dist.barrier()
+            al.close()
+        q.put((rank, out))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_wide_bands_with_pruning_against_the_single_partition(pkg):
+    """Two bands of 120 000 columns (two processes, column port between them) -- wide enough for the packed kernel's
+    hot chunk loop and for runs of pruned slabs taken 16 at a time, with a first column that arrives through the port --
+    against ONE partition on the int32 kernels: same best cell; unpruned, the concatenated special-row slices are the single
+    partition's rows cell for cell; pruned, lower bounds of them (H and F)."""
+    import numpy as np
+    m, n, world = 150000, 240000, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_wide, args=(r, world, port, m, n, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=800) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    s0, s1 = pkg.seqgen.related_pair(m, n, cfg=73)
+    al = pkg.MI355Aligner(device=0, rows_per_lane=16, flags=2)
+    try:
+        al.setSequences(s0, s1)
+        part = pkg.Partition(0, 0, m, n)
+        mg = pkg.Stage1Manager(part, special_row_interval=32768)
+        al.alignPartition(part, mg)
+        i, j, sc = mg.getBestScore()
+        want = (i - 1, j - 1, sc)                         # the band runner reports the 0-based cell
+        single = {dp: mg.specialRow(dp) for dp in sorted(mg.special_rows) if dp < m}
+    finally:
+        al.close()
+    assert len(single) >= 3 and want[2] > 50000
+    for mode in ("plain", "pruned"):
+        assert all(res[r][mode]["best"] == want for r in range(world)), (mode, [res[r][mode]["best"] for r in range(world)], want)
+        assert all(res[r][mode]["restarts"] == 0 and res[r][mode]["kernel"] == 2 for r in range(world)), mode
+        for dp, row in single.items():
+            got = np.concatenate([res[r][mode]["rows"][dp][1] for r in range(world)])
+            if mode == "plain":
+                assert np.array_equal(got, row[1:]), dp
+            else:
+                assert np.all(got <= row[1:]), dp
+    assert all(res[r]["plain"]["pruned"] == 0 for r in range(world))
+    assert sum(res[r]["pruned"]["pruned"] for r in range(world)) > 0.15 * m * n
