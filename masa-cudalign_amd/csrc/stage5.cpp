@@ -3,6 +3,8 @@
 // Replaces M/stage5/sw_stage5.cpp (sw() :83-319, the loop of stage5() :322-485) -- single-threaded CPU code in the
 // reference too; a 10 M-column alignment is ~700 k partitions of <= 256 cells, milliseconds here.
 // The caller (masa-cudalign_amd/stage56.py) turns the gap events into Alignment.cpp's gap lists.
+// Second half of this file: stage 6's text (mi355sw_stage6_text) -- host code of the same kind, kept in the same
+// translation unit so that the build recipe, which is part of the kernels' build identity, stays as it is.
 #include "../../include/mi355sw.h"
 
 #include <cstdlib>
