@@ -158,3 +158,68 @@ def test_score_only_pass_with_mixed_heights_agrees_with_int32(pkg):
             al.close()
     assert res[0][0] == res[2][0]
     assert res[0][1]["profile_kernel"] == 2
+
+
+def _fuzz_wide(k):
+    rng = np.random.default_rng(7000 + k)
+    m = int(rng.integers(20000, 220000))
+    n = int(rng.integers(40000, 320000))
+    sub = float(rng.choice([0.01, 0.04, 0.10, 0.20]))
+    src = ACGT[rng.integers(0, 4, size=max(m, n) + 4096)]
+    s1 = src[:n].copy()
+    # seq0: a mutated copy of a window of the common source (ridge somewhere in the matrix), sometimes two windows glued
+    off = int(rng.integers(0, max(1, n - m // 2)))
+    base = np.concatenate([src[off:], src[:off]])[:m].copy()
+    mut = rng.random(m) < sub
+    base[mut] = ACGT[rng.integers(0, 4, size=int(mut.sum()))]
+    if rng.random() < 0.4:                                       # a block of unrelated sequence in the middle
+        a = int(rng.integers(0, m - 1000))
+        ln = min(int(rng.integers(500, 20000)), m - a)
+        base[a:a + ln] = ACGT[rng.integers(0, 4, size=ln)]
+    if rng.random() < 0.3:
+        p = int(rng.integers(17000, n - 200))
+        s1[p:p + int(rng.integers(1, 150))] = ord("N")
+    R = int(rng.choice([0, 4, 8, 12, 16, 24, 32]))
+    mode = ["sw", "sw_prune", "sw_prune", "nw", "semi"][int(rng.integers(0, 5))]
+    interval = int(rng.choice([0, 0, 16384, 65536]))
+    return m, n, np.ascontiguousarray(base), np.ascontiguousarray(s1), R, mode, interval
+
+
+@pytest.mark.parametrize("k", range(96))
+def test_randomised_wide_runs_against_the_int32_kernels(pkg, k):
+    """96 seeded wide configurations (20 000-220 000 rows x 40 000-320 000 columns, related pairs with 1-20 % substitutions,
+    runs of N, every strip height; local with and without pruning, global, semi-global; with and without special rows):
+    the packed kernels (hot chunk loop, runs of pruned slabs) against the int32 kernels, which have neither -- same best
+    cell; without pruning the same last row, last column and special rows, cell for cell; with pruning lower bounds."""
+    m, n, s0, s1, R, mode, interval = _fuzz_wide(k)
+    start, end = {"sw": (0, 0), "sw_prune": (0, 0), "nw": (4, 4), "semi": (1, 3)}[mode]
+    part = pkg.Partition(0, 0, m, n)
+    res = {}
+    for flags in (0, 2):
+        # the int32 family has strips of 256 / 512 / 1024 rows: special rows need the same rows on both sides
+        rpl = R if (interval == 0 or R in (4, 8, 16)) else 16
+        al = pkg.MI355Aligner(device=0, flags=flags, rows_per_lane=rpl if flags == 0 or rpl in (4, 8, 16) else 0)
+        try:
+            al.setSequences(s0, s1)
+            mg = pkg.Stage1Manager(part, alignment_start=getattr(pkg, EDGE[start]), alignment_end=getattr(pkg, EDGE[end]),
+                                   keep_last_row=True, keep_last_column=True, special_row_interval=interval,
+                                   block_pruning=(mode == "sw_prune" and flags == 0))
+            al.alignPartition(part, mg)
+            st = al.getStatistics()
+            rows = {i: mg.specialRow(i) for i in sorted(mg.special_rows) if i < m}
+            res[flags] = (tuple(mg.getBestScore()), mg.lastRow(), mg.lastColumn(), st, rows)
+        finally:
+            al.close()
+    assert res[0][3]["profile_kernel"] == 2 and res[2][3]["profile_kernel"] == 1
+    assert res[0][0] == res[2][0], (mode, m, n, R)
+    pruned = mode == "sw_prune" and res[0][3]["pruned_cells"] > 0
+    if interval:
+        assert sorted(res[0][4]) == sorted(res[2][4])
+    if pruned:
+        assert np.all(res[0][1] <= res[2][1]) and np.all(res[0][2] <= res[2][2])
+        for i in res[0][4]:
+            assert np.all(res[0][4][i] <= res[2][4][i]), i
+    else:
+        assert np.array_equal(res[0][1], res[2][1]) and np.array_equal(res[0][2], res[2][2])
+        for i in res[0][4]:
+            assert np.array_equal(res[0][4][i], res[2][4][i]), i
