@@ -8,7 +8,7 @@
 One "step" = one complete Stage-1 pass (score + canonical position) over the synthetic pair with both
 sequences already resident in HBM.
   N = 1 : BASELINE config C2, 3,000,000 x 3,000,000 unrelated random ACGT, local SW, score-only.
-  N > 1 : weak scaling, per-GPU work fixed at 3.6e13 cells: (12,000,000*N) x 3,000,000 (tall like BASELINE's C4/C5:
+  N > 1 : weak scaling, per-GPU work fixed at 7.2e13 cells: (24,000,000*N) x 3,000,000 (tall like BASELINE's C4/C5:
           the start-up of a chain of column bands is N-1 band sweeps, whatever the height), seq1 cut into N column
           bands; the boundary column goes GPU to GPU through column ports (bands.py transport "p2p": band g's strip
           kernel stores its last column into band g+1's HBM over xGMI and publishes the row count, band g+1's kernel
@@ -127,7 +127,7 @@ def main():
     ap.add_argument("--size", type=int, default=3000000, help="n (and m per GPU) of the synthetic pair")
     ap.add_argument("--rows-per-lane", type=int, default=int(os.environ.get("MI355SW_R", "0")))
     ap.add_argument("--waves", type=int, default=int(os.environ.get("MI355SW_WAVES", "0")))
-    ap.add_argument("--tall", type=int, default=4, help="N > 1: rows per GPU = tall * size (weak scaling)")
+    ap.add_argument("--tall", type=int, default=8, help="N > 1: rows per GPU = tall * size (weak scaling)")
     ap.add_argument("--related", action="store_true",
                     help="a RELATED synthetic pair (2 %% substitutions, indels, one inversion) with block pruning on in every "
                          "band against the chain-wide best score: GCUPS in the reference's m*n convention plus the pruned fraction")
