@@ -96,3 +96,21 @@ def test_band_loop_gives_up_on_a_stalled_band(pkg, monkeypatch):
     with pytest.raises(RuntimeError, match="band 0/1: no progress"):
         runner.run(1000, 0, 500)
     assert eng.aborted and eng.ended
+
+
+def test_crosspoint_array_writer_equals_the_object_writer(pkg, tmp_path):
+    """crosspoints.save_array (millions of points at C3's size: no object per point) writes the bytes CrosspointsFile.save
+    writes for the same points (M/common/CrosspointsFile.cpp:152-160: START, type,i,j,score per line, END)"""
+    import numpy as np
+    from masa_cudalign_amd.crosspoints import Crosspoint, CrosspointsFile, save_array
+    rng = np.random.default_rng(5)
+    pts = np.stack([rng.integers(0, 3, 1000), np.sort(rng.integers(0, 10 ** 8, 1000)), np.sort(rng.integers(0, 10 ** 8, 1000)),
+                    rng.integers(-10 ** 7, 10 ** 8, 1000)], axis=1).astype(np.int32)
+    a, b = str(tmp_path / "a"), str(tmp_path / "b")
+    f = CrosspointsFile(a)
+    f.extend(Crosspoint(int(i), int(j), int(s), int(t)) for (t, i, j, s) in pts)
+    f.save()
+    save_array(b, pts)
+    assert open(a, "rb").read() == open(b, "rb").read()
+    save_array(b, [tuple(int(x) for x in r) for r in pts[:3]])            # a list of tuples is taken as well
+    assert open(b).read().split()[1] == "%d,%d,%d,%d" % tuple(pts[0])
