@@ -223,7 +223,8 @@ class BandRunner:
         n_total: width of the whole matrix (default j1 of the last band = this band's j1): block pruning bounds what an
         alignment can still gain by the rows and columns left in the SUPER-partition (M3).
         keep_inbound: leave the whole boundary column this band received, corner cell first, in self.inbound_column
-        ((m+1, 2) cells (H,E)) -- what the reference tees into C00000000.INIT_WITH_CUSTOM_DATA (sw_stage1.cpp:186-191)."""
+        ((m+1, 2) cells (H,E)) -- what the reference tees into C00000000.INIT_WITH_CUSTOM_DATA (sw_stage1.cpp:186-191);
+        8 bytes of host memory per row (2 GB at C5's 249 M rows), like the file it becomes."""
         import zlib
         from .engine import AlignerError
         self.inbound_crc = 0 if digest_inbound else None
