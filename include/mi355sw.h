@@ -216,8 +216,15 @@ typedef struct {
                                            AbstractDiagonalAligner::isSpecialRow :466-478) */
     int32_t track_best;                 /* mustDispatchScores() */
     int32_t force_int32;                /* 1: int32 kernel even where the packed 16-bit one applies */
-    int32_t prune_blocks;               /* mustPruneBlocks(): skip 64-column slabs of a strip that cannot reach the
-                                           running best (AbstractBlockPruning::isBlockPrunable, SW only) */
+    int32_t prune_blocks;               /* mustPruneBlocks(): skip 64-column slabs of a strip that cannot matter
+                                           (AbstractBlockPruning::isBlockPrunable, AbstractBlockPruning.cpp:70-111).
+                                           SMITH_WATERMAN: slabs that cannot reach the running best score.
+                                           NEEDLEMAN_WUNSCH: the caller states that the alignment is GLOBAL -- its score is
+                                           read from the LAST cell of the super-partition -- and slabs through which no
+                                           path can reach a running lower bound of that cell are skipped (:92-104: gap terms
+                                           + the lower bound `score - dec`); honoured only with track_best = 0.  Skipped
+                                           cells read H = 0 (local) or -INF (global) with E = F = -INF, lower bounds of
+                                           the true cells; every cell an optimal path can use stays exact. */
     int32_t prune_rows, prune_cols;     /* rows/columns left from the partition origin to the end of the
                                            SUPER-partition (max_i - i0, max_j - j0); 0 = the partition's own */
     int32_t first_column_port;          /* 1: the first column arrives in this handle's inbound column port, written by

@@ -235,7 +235,9 @@ class BandRunner:
         part = Partition(0, j0, m, j1)
         seg = self.segment_rows
         nseg = (m + seg - 1) // seg
-        prune = bool(self.prune_blocks and recurrence == SMITH_WATERMAN and track_best)
+        # local alignments prune against the chain's running best score; global ones (NEEDLEMAN_WUNSCH with nothing tracked:
+        # the answer is the last cell of the last band) against a running lower bound of that cell, AbstractBlockPruning.cpp:92-109
+        prune = bool(self.prune_blocks and (track_best if recurrence == SMITH_WATERMAN else not track_best))
         kw = dict(recurrence_type=recurrence, track_best=track_best,
                   first_row_init_type=first_row_init_type, first_row_start_offset=j0,
                   want_last_column=(not last) and not p2p, last_column_port=(not last) and p2p,
@@ -440,6 +442,8 @@ class BandRunner:
                 except AlignerError as e:
                     if "EOVERFLOW16" not in str(e) or kw.get("force_int32") or self.restarts > 0:
                         raise
+                    if os.environ.get("MI355SW_VERBOSE"):
+                        print("[bands] band %d/%d restarts on the int32 kernels: %s" % (self.rank, self.world, e), file=sys.stderr)
                     restart_int32()
                     continue
                 # (device-resident rows are read through the copy stream: only once nothing more has to be fed, so that

@@ -184,38 +184,51 @@ static __device__ __forceinline__ void relay_running_best(const UniformArgs a) {
 
 // Ordered completion: strips_done == s+1 means strips 0..s are complete and their last-column / special-row /
 // best records are visible (system scope) to the host -- and, through the column port, to the next band's GPU.
-static __device__ __attribute__((noinline, unused)) void complete_strip_common(const KernelArgs* ap, const int s_in, const int lane, const int strip_rows) {
+// `stopped_waves_leave`: the kernel's wavefronts leave the persistent loop when they find a stop at their claim (the
+// one-partition kernels), so after a stop the counter may never reach s -- a wavefront that claimed ticket s and saw the
+// stop is gone, while the holder of ticket s+1, whose poll came a moment earlier, swept its strip.  That wavefront must
+// not sit out the spin limit here (10-20 s) nor turn the stop into a time-out: once a stop is set it leaves, publishing
+// nothing but the error mirror.  (The batch kernel takes every ticket through here in order, stopped or not, and the
+// host counts on that: there the counter always arrives.)
+static __device__ __attribute__((noinline, unused)) void complete_strip_common(const KernelArgs* ap, const int s_in, const int lane, const int strip_rows,
+                                                                                const bool stopped_waves_leave) {
     const UniformArgs a = uniform_args(ap);
     const int s = sync::rfl(s_in);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
     int spins = 0;
     // a band fed from outside may legitimately stand still for as long as its first column takes to arrive
     const int spin_limit = a->first_col_ready != nullptr ? (1 << 30) : (1 << 24);
+    bool gone = false;                 // stopped while waiting for a predecessor that will never count itself
     while (sync::poll_dev(a->strips_done_dev) != s && spins < spin_limit) {
         __builtin_amdgcn_s_sleep(8);
         spins++;
+        if (stopped_waves_leave && (spins & 31) == 0 &&
+            (sync::poll_dev(a->abort_flag) != 0 || (a->host_abort != nullptr && sync::poll_system(a->host_abort) != 0))) { gone = true; break; }
     }
     if (lane == 0) {
-        if (spins >= spin_limit) atomicExch(a->error_flag, 3);
-        relay_running_best(a);
+        // (never over a report that is already there: an overflow code 16 must reach the host as such)
+        if (spins >= spin_limit) atomicCAS(a->error_flag, 0, 3);
+        if (!gone) relay_running_best(a);
         const int err = __hip_atomic_load(a->error_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (err != 0 && a->host_error != nullptr) {
             // low byte: the code; above it, for an overflow report of the packed kernel, its causes (error_flag[1])
             const int why = __hip_atomic_load(a->error_flag + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(a->host_error, err | (why << 8), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
-        if (a->peer_ready != nullptr && err == 0 &&
-            __hip_atomic_load(a->abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0 &&
-            (a->host_abort == nullptr || __hip_atomic_load(a->host_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0)) {
-            long long rows = (long long) a->strip_row0 + (long long) (s + 1) * strip_rows;
-            if (rows > a->m) rows = a->m;
-            // the strip's last-column cells were stored into the neighbour's HBM by every lane before the
-            // system-scope release fence above; this is the flag that follows them over xGMI
-            __hip_atomic_store(a->peer_ready, (int) rows, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (!gone) {
+            if (a->peer_ready != nullptr && err == 0 &&
+                __hip_atomic_load(a->abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0 &&
+                (a->host_abort == nullptr || __hip_atomic_load(a->host_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0)) {
+                long long rows = (long long) a->strip_row0 + (long long) (s + 1) * strip_rows;
+                if (rows > a->m) rows = a->m;
+                // the strip's last-column cells were stored into the neighbour's HBM by every lane before the
+                // system-scope release fence above; this is the flag that follows them over xGMI
+                __hip_atomic_store(a->peer_ready, (int) rows, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+            if (a->strips_done_host != nullptr)
+                __hip_atomic_store(a->strips_done_host, s + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(a->strips_done_dev, s + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        if (a->strips_done_host != nullptr)
-            __hip_atomic_store(a->strips_done_host, s + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        __hip_atomic_store(a->strips_done_dev, s + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __builtin_amdgcn_wave_barrier();
 }

@@ -387,7 +387,7 @@ sw_strip_kernel(const KernelArgs* __restrict__ ap) {
         } else {
             process_strip<R, SW, PROFILE, TRACK>(ap, s, lds, lane);
         }
-        complete_strip_common(ap, s, lane, 64 * R);
+        complete_strip_common(ap, s, lane, 64 * R, true);
     }
 }
 

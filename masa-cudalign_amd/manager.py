@@ -261,8 +261,11 @@ class Stage1Manager:
                                        sup.i1 - sup.i0, sup.j1 - sup.j0)
         self.special_row_interval = special_row_interval
         self.keep_last_row, self.keep_last_column = keep_last_row, keep_last_column
-        # sw_stage1.cpp:219-225: pruning only when the alignment may end anywhere
-        self.block_pruning = block_pruning and alignment_end == AT_ANYWHERE
+        # sw_stage1.cpp:219-225: pruning only when the alignment may end anywhere -- and, beyond the reference's stage 1
+        # (which holds the bound, AbstractBlockPruning.cpp:92-109, but never asks for it), for global alignments: both
+        # ends in the corners, the goal is the last cell
+        self.block_pruning = block_pruning and (alignment_end == AT_ANYWHERE or
+                                                (alignment_start == AT_SEQUENCE_1_AND_2 and alignment_end == AT_SEQUENCE_1_AND_2))
         # special rows / last row go to disk when a SpecialRowsPartition is given (AlignerManager::dispatchRow ->
         # SpecialRowsPartition::write, AlignerManager.cpp:334-356); the status file follows every completed row
         self.sra, self.status = sra_partition, status

@@ -81,6 +81,11 @@ CASES = [
     # stages 2-6 must come out identical
     dict(name="full_pipeline_pruned_60000x50000_b8192", seq=dict(kind="related", m=60000, n=50000, cfg=31),
          args=["--disk-size=4M", "--block=8192,1024"], full=True, pruned=True),
+    # GLOBAL alignment through all six stages (round 4).  The reference never prunes a global stage 1
+    # (sw_stage1.cpp:219-225); the engine does (AbstractBlockPruning.cpp:92-109, per slab) -- its special rows are then
+    # lower bounds off every optimal path, and stages 2-6 on top of them must reproduce these files
+    dict(name="full_pipeline_global_60000x50000_b8192", seq=dict(kind="related", m=60000, n=50000, cfg=34),
+         args=["--edges=++", "--disk-size=4M", "--block=8192,1024"], full=True),
 ]
 
 CHAIN = dict(name="sw_chain3_9000x9000", seq=dict(kind="related", m=9000, n=9000, cfg=11), parts=3)
@@ -89,7 +94,16 @@ CHAIN = dict(name="sw_chain3_9000x9000", seq=dict(kind="related", m=9000, n=9000
 def main():
     assert oracle.have_ref(), "build oracle/_ref first (oracle/build_ref.sh)"
     out = {"generator": "oracle/make_golden.py", "reference": "masa-cudalign-4.0.2.1028 MASA-Core CPU path", "cases": []}
+    path = os.path.join(ROOT, "tests", "golden", "stage1_cases.json")
+    # `--add`: only the cases the committed file does not hold yet are run and appended (everything else stays as it is)
+    add_only = "--add" in sys.argv[1:]
+    if add_only:
+        with open(path) as f:
+            out = json.load(f)
+    have = set(c["name"] for c in out["cases"])
     for case in CASES:
+        if case["name"] in have:
+            continue
         s0, s1 = make_pair(case["seq"])
         ref = oracle.run_ref(s0, s1, case["args"])
         rec = {"name": case["name"], "seq": case["seq"], "args": case["args"], "m": len(s0), "n": len(s1),
@@ -117,6 +131,11 @@ def main():
             rec["special_rows"] = {str(i): cells_digest(a) for (d, i), a in sorted(ref["special_rows"].items())}
         out["cases"].append(rec)
         print(case["name"], rec["best"], flush=True)
+    if add_only:
+        with open(path, "w") as f:
+            json.dump(out, f, indent=1)
+        print("wrote", path)
+        return
     # chained column bands: --split=N --part=k with file:// boundary columns (libmasa.cpp:497-535)
     import shutil
     import tempfile
@@ -143,7 +162,6 @@ def main():
         print("chain", bests, single["best"], list(cols))
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
-    path = os.path.join(ROOT, "tests", "golden", "stage1_cases.json")
     with open(path, "w") as f:
         json.dump(out, f, indent=1)
     print("wrote", path)

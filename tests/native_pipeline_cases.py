@@ -24,6 +24,12 @@ CASES = {
     # 1024-row strips like the drop-in test's --strip-rows=1024 (rows_per_lane = rows / 64)
     "pruned_60000x50000": ("full_pipeline_pruned_60000x50000_b8192", dict(rows_per_lane=16),
                            dict(sra_limit=4 * 1024 * 1024, block_pruning=True), True),
+    # GLOBAL alignment (--alignment-edges=++), stage 1 with block pruning -- the reference run of the fixture did not prune
+    # (its stage 1 never does for global alignments); special rows off the optimal paths are lower bounds here
+    "global_pruned_60000x50000": ("full_pipeline_global_60000x50000_b8192", dict(rows_per_lane=16),
+                                  dict(sra_limit=4 * 1024 * 1024, block_pruning=True, alignment_start=4, alignment_end=4), True),
+    "global_unpruned_60000x50000": ("full_pipeline_global_60000x50000_b8192", dict(rows_per_lane=16),
+                                    dict(sra_limit=4 * 1024 * 1024, block_pruning=False, alignment_start=4, alignment_end=4), True),
 }
 
 
@@ -57,8 +63,11 @@ def run(case_name):
         checks["start_and_end"] = bool(cp2) and cp2[0] == want2[0] and cp2[-1] == want2[-1]
     if pkw.get("block_pruning"):
         checks["pruned"] = out["stage1"]["pruned_cells"] > 0.15 * case["m"] * case["n"]
+    if "crosspoints_4" in case and exact:
+        checks["crosspoints_4"] = hashlib.sha256(open(crosspoint_file(work, 4), "rb").read()).hexdigest() == case["crosspoints_4"]["file_sha256"]
     res = {"case": case_name, "checks": checks, "ok": all(checks.values()), "best": list(out["best"]),
-           "crosspoints": out["crosspoints"], "seconds": out["seconds"], "stage3_rounds": out["stage3"]["rounds"]}
+           "crosspoints": out["crosspoints"], "seconds": out["seconds"], "stage3_rounds": out["stage3"]["rounds"],
+           "pruned_fraction": out["stage1"]["pruned_cells"] / float(case["m"]) / case["n"]}
     print(json.dumps(res), flush=True)
     return 0 if res["ok"] else 1
 

@@ -56,6 +56,18 @@ def test_native_pipeline_with_pruning_biting():
     assert res["checks"]["pruned"] and res["checks"]["alignment_txt"]
 
 
+def test_native_pipeline_global_alignment_with_pruning():
+    """--alignment-edges=++ through all six stages with block pruning ON in stage 1 (BASELINE config 5 as worded: the
+    reference holds the bound, AbstractBlockPruning.cpp:92-109, but its stage 1 never asks for it, sw_stage1.cpp:219-225):
+    more than a quarter of the matrix is skipped, the special rows are lower bounds off the optimal paths -- and best
+    score, stage-2 crosspoints, crosspoint_04 and alignment.00.txt are the files MASA-Core wrote WITHOUT pruning."""
+    res = _case("global_pruned_60000x50000", limit_s=400)
+    assert res["checks"]["pruned"] and res["checks"]["alignment_txt"] and res["checks"]["crosspoints_2"] and res["checks"]["crosspoints_4"]
+    assert res["pruned_fraction"] > 0.25
+    res = _case("global_unpruned_60000x50000", limit_s=400)
+    assert res["checks"]["alignment_txt"] and res["pruned_fraction"] == 0
+
+
 def test_native_pipeline_equals_the_dropin_at_4M():
     """4 000 000 x 4 000 000 related pair, pruning biting, special rows on disk: native stages 1-6 = MASA-Core's own
     stages on the same engine (crosspoint files and alignment.00.txt byte for byte), alignment re-scores to the best"""

@@ -50,7 +50,10 @@ def test_pipeline_reproduces_the_fixture(case, pkg, oracle, tmp_path):
     s0, s1 = make_pair(pkg, case["seq"])
     q0, q1 = _fasta(pkg, s0, s1)
     work = str(tmp_path / "work")
-    out = pipeline.align(_double(oracle, case["args"]), q0, q1, work, sra_limit=_limit(case["args"]), block_pruning=False)
+    from helpers import parse_args
+    edges = parse_args(case["args"])                      # --edges=++ (a global alignment) in one of the fixtures
+    out = pipeline.align(_double(oracle, case["args"]), q0, q1, work, sra_limit=_limit(case["args"]), block_pruning=False,
+                         alignment_start=edges["start"], alignment_end=edges["end"])
     assert list(out["best"]) == case["best"]
     cp2 = CrosspointsFile(crosspoint_file(work, 2)).load().tuples()
     cp3 = CrosspointsFile(crosspoint_file(work, 3)).load().tuples()
