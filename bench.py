@@ -131,7 +131,11 @@ def main():
     ap.add_argument("--related", action="store_true",
                     help="a RELATED synthetic pair (2 %% substitutions, indels, one inversion) with block pruning on in every "
                          "band against the chain-wide best score: GCUPS in the reference's m*n convention plus the pruned fraction")
+    ap.add_argument("--nw", action="store_true",
+                    help="GLOBAL alignment (Needleman-Wunsch, gap-initialised borders: BASELINE config 5's recurrence) instead of a "
+                         "local one; with --related, block pruning against a running lower bound of H[m][n] shared along the chain")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-shapes", action="store_true", help="N = 1: skip the C3- and C5-shaped checks (c3_shape, c5_shape)")
     ap.add_argument("--no-target-shape", action="store_true", help="N = 1: skip the 228 M-row north-star-height step")
     ap.add_argument("--no-single-reference", action="store_true",
                     help="N > 1: skip rank 0's untimed run of ONE GPU's share of the cells (tall*size x size) alone")
@@ -260,7 +264,16 @@ def main():
         dist.barrier()
 
     def one_step():
-        best = runner.run(m, j0, j1, n_total=n)
+        if args.nw:
+            # global alignment: gap-initialised borders, nothing tracked, the answer is the last band's last cell
+            from masa_cudalign_amd.engine import NEEDLEMAN_WUNSCH, INIT_WITH_GAPS, INF
+            got, last = {}, rank == world - 1
+            runner.run(m, j0, j1, n_total=n, recurrence=NEEDLEMAN_WUNSCH, track_best=False, first_row_init_type=INIT_WITH_GAPS,
+                       first_col_init_type=INIT_WITH_GAPS, want_last_row=last,
+                       before_end=(lambda eng: got.update(h=int(eng.streamReadLastRow(col=j1 - j0 - 1, length=1)[0, 0]))) if last else None)
+            best = (m - 1, n - 1, got["h"]) if last else (-1, -1, -INF)
+        else:
+            best = runner.run(m, j0, j1, n_total=n)
         if world > 1:
             best = runner.reduce_best(best)
         return best, al.getStatistics()
@@ -308,8 +321,8 @@ def main():
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9
         band_cells = float(m) * float(j1 - j0)
         kname = "pk16" if st["profile_kernel"] == 2 else "int32"
-        # two strip heights in one launch (sw_strip_kernel_pk16_mixed): more strips than one height would need
-        mixed = st["profile_kernel"] == 2 and world == 1 and (st["strips"] - 1) * st["strip_rows"] >= m
+        # two strip heights in one launch (sw_strip_kernel_pk16_mixed): the library says so itself (mi355sw_stats, ABI 5)
+        mixed = st["strip_rows_second"] > 0
         pmc = pmc_lookup(kname, m, j1 - j0, st["strip_rows"]) if world == 1 else None
         out = {
             "metric": "GCUPS (DP cells/sec) Stage-1", "value": gcups, "unit": "GCUPS",
@@ -317,13 +330,16 @@ def main():
             "ms_per_step": dt * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "i16x2 (packed, exact; int32 fallback)" if st["profile_kernel"] == 2 else "int32",
             "data": "synthetic",
-            "config": {"workload": (("C2: %dx%d unrelated random ACGT, local SW, score-only" % (m, n)) if not args.related else
-                                    ("%dx%d RELATED synthetic pair, local SW, score-only, block pruning on" % (m, n))) if world == 1 else
-                       ("weak scaling, %d x C2's cells per GPU: (%d*%d)x%d %s, local SW, score-only; "
+            "config": {"workload": (("C2: %dx%d unrelated random ACGT, local SW, score-only" % (m, n)) if not (args.related or args.nw) else
+                                    ("%dx%d %s synthetic pair, %s, score-only%s" % (m, n, "RELATED" if args.related else "unrelated",
+                                                                                 "global NW (gap-initialised borders)" if args.nw else "local SW",
+                                                                                 ", block pruning on" if args.related else ""))) if world == 1 else
+                       ("weak scaling, %d x C2's cells per GPU: (%d*%d)x%d %s, %s, score-only; "
                         "%d column bands of %d columns, boundary column GPU to GPU (%s)"
                         % (args.tall, args.size * args.tall, world, n,
-                           "RELATED synthetic pair, block pruning on against the chain-wide best" if args.related else "unrelated random ACGT",
-                           world, n // world, comm)),
+                           ("RELATED synthetic pair, block pruning on against the chain-wide %s" % ("lower bound of H[m][n]" if args.nw else "best"))
+                           if args.related else "unrelated random ACGT",
+                           "global NW (gap-initialised borders)" if args.nw else "local SW", world, n // world, comm)),
                        "m": m, "n": n, "bands": world, "strip_rows": st["strip_rows"], "waves_per_gpu": st["waves"],
                        "kernel": {2: "pk16", 1: "int32-profile", 0: "int32-generic"}[st["profile_kernel"]],
                        "comm": comm if world > 1 else "none", "comm_note": comm_note,
@@ -332,7 +348,9 @@ def main():
                        "xgmi": bool(world > 1 and comm == "p2p" and not rehearse),
                        "collectives": ({"backend": dist.get_backend(), "world": dist.get_world_size()} if world > 1 else None),
                        "ranks": ranks, "same_shape_single_gpu": single_ref,
-                       "related_pair": bool(args.related),
+                       "related_pair": bool(args.related), "recurrence": "NW" if args.nw else "SW",
+                       "kernel_name": st["kernel"], "strips": st["strips"], "strips_first": st["strips_first"],
+                       "strip_rows_second": st["strip_rows_second"], "restarts": runner.restarts,
                        "pruned_fraction": ((sum(r["pruned_cells"] for r in ranks) if ranks else sum(pruned) / len(pruned)) / (float(m) * n)), "kernel_build_id": kernel_build_id(), "build_identity": build_identity()},
             "best": {"i": best[0] + 1, "j": best[1] + 1, "score": best[2]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -340,11 +358,11 @@ def main():
                          "traffic": pmc["traffic_bytes"] if pmc else None,
                          "traffic_source": (pmc["source"] + " (rocprofv3 --pmc passes on this kernel build, bytes per launch)") if pmc
                                            else "not measured on this kernel build (profiles/pmc_index.json has no entry)",
-                         "kernel": ("sw_strip_kernel_pk16_mixed<12,11,true,true>" if mixed else "sw_strip_kernel_pk16") if st["profile_kernel"] == 2 else "sw_strip_kernel",
+                         "kernel": st["kernel"],
                          "strips": st["strips"],
                          "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_bytes,
                          "note": ("scan kernel: 17 B per column per strip (%d strips of %s rows); the binding unit is VALU issue"
-                                  % (st["strips"], "1536 and 1408" if mixed else str(st["strip_rows"])))},
+                                  % (st["strips"], ("%d and %d" % (st["strip_rows"], st["strip_rows_second"])) if mixed else str(st["strip_rows"])))},
             "valu_roofline": _valu(st, band_cells, k_ms, pmc),
         }
         # the extras must never cost the headline line: whatever goes wrong in them is reported inside the JSON
@@ -353,6 +371,12 @@ def main():
                 out["target_shape"] = target_shape(pkg, local_rank, check=not args.no_cpu_baseline)
             except Exception as e:                       # noqa: BLE001
                 out["target_shape"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        if world == 1 and not args.no_shapes:
+            for key, fn in (("c3_shape", c3_shape), ("c5_shape", c5_shape)):
+                try:
+                    out[key] = fn(pkg, local_rank)
+                except Exception as e:                   # noqa: BLE001
+                    out[key] = {"error": "%s: %s" % (type(e).__name__, e)}
         if world == 1 and not args.no_cpu_baseline:
             for key, fn in (("cpu_baseline", cpu_baseline), ("cpu_baseline_all_cores", cpu_baseline_mt)):
                 try:
@@ -393,6 +417,91 @@ def target_shape(pkg, device, check=True):
         ref = oracle.stage1(s0[i0:i], s1[j0:j], want_last_row=True)
         out["check"] = {"oracle_window": "600x600 ending at the reported cell",
                         "ok": bool(ref["best"][2] == best[2] and int(ref["last_row"][-1][0]) == best[2])}
+    return out
+
+
+def _sha(a):
+    import hashlib
+    import numpy as np
+    return hashlib.sha256(np.ascontiguousarray(a, dtype=np.int32).tobytes()).hexdigest()
+
+
+def c3_shape(pkg, device):
+    """BASELINE config 3's kind of work in the driver-run line: the first 1 M columns of a 48 M x 46 M RELATED pair (C3's
+    height; the band's pruning bound looks at the whole 46 M columns like band 0 of a chain would), local SW with special
+    rows, once without and once with block pruning.  The pruned run must report the same best cell, and its special rows
+    must be lower bounds of the unpruned ones (sha256 of those recorded) with the row maximum intact above the best cell."""
+    import numpy as np
+    from masa_cudalign_amd.bands import BandRunner
+    m, n, n_total = 48000000, 1000000, 46000000
+    s0, s1 = pkg.seqgen.related_pair(m, n, cfg=3)
+    out = {"workload": "C3-shaped: %dx%d band of a related pair (bound against %d columns), local SW, special rows every 8 Mi rows, "
+                       "without and with block pruning" % (m, n, n_total)}
+    res = {}
+    al = pkg.MI355Aligner(device=device)
+    try:
+        al.setSequences(s0, s1)
+        for prune in (False, True):
+            rows = {}
+            t0 = time.time()
+            br = BandRunner(al, prune_blocks=prune)
+            best = br.run(m, 0, n, special_row_interval=8 << 20, n_total=n_total,
+                          special_row_sink=lambda dp, c0, cells: rows.__setitem__(dp, cells.copy()))
+            dt = time.time() - t0
+            st = al.getStatistics()
+            st["restarts"] = br.restarts
+            res[prune] = (best, rows)
+            out["pruned" if prune else "plain"] = {"value": float(m) * n / dt / 1e9, "unit": "GCUPS (m*n)", "seconds": dt, "kernel_ms": st["kernel_ms"],
+                                                   "kernel": st["kernel"], "strip_rows": st["strip_rows"], "restarts": st["restarts"],
+                                                   "pruned_fraction": st["pruned_cells"] / float(m) / n,
+                                                   "best": {"i": best[0] + 1, "j": best[1] + 1, "score": best[2]}}
+    finally:
+        al.close()
+    (b0, r0), (b1, r1) = res[False], res[True]
+    out["special_rows"] = {str(dp): _sha(r0[dp]) for dp in sorted(r0)}
+    lower = all(bool(np.all(r1[dp] <= r0[dp])) for dp in r0)
+    maxima = all(int(r1[dp][:, 0].max()) == int(r0[dp][:, 0].max()) for dp in r0 if dp <= b0[0])
+    out["check"] = {"same_best_cell": tuple(b0) == tuple(b1), "same_rows": sorted(r0) == sorted(r1) and len(r0) >= 4,
+                    "pruned_rows_are_lower_bounds": lower, "row_maxima_above_the_best_cell_intact": maxima}
+    out["check"]["ok"] = all(out["check"].values())
+    return out
+
+
+def c5_shape(pkg, device):
+    """BASELINE config 5's kind of work: 249 M rows (C5's height) x 256 k columns, GLOBAL NW with gap-initialised
+    borders.  The packed kernel's H[m][n] and last row (sha256) must be the int32 kernel's; then the same band as band 0
+    of C5 (the bound looks at all 228 M columns) with block pruning: lower bounds of the unpruned last row."""
+    import numpy as np
+    from masa_cudalign_amd.bands import BandRunner
+    from masa_cudalign_amd.engine import NEEDLEMAN_WUNSCH, INIT_WITH_GAPS
+    m, n, n_total = 249000000, 262144, 228000000
+    s0, s1 = pkg.seqgen.related_pair(m, n, cfg=5)
+    out = {"workload": "C5-shaped: %dx%d global NW, gap-initialised borders; packed kernel against the int32 kernel, then with block "
+                       "pruning as band 0 of %d columns" % (m, n, n_total)}
+    rows = {}
+    for key, flags, prune in (("packed", 0, False), ("int32", 2, False), ("packed_pruned", 0, True)):
+        al = pkg.MI355Aligner(device=device, flags=flags)
+        try:
+            al.setSequences(s0, s1)
+            got = {}
+            t0 = time.time()
+            br = BandRunner(al, prune_blocks=prune)
+            br.run(m, 0, n, recurrence=NEEDLEMAN_WUNSCH, track_best=False, first_row_init_type=INIT_WITH_GAPS,
+                   first_col_init_type=INIT_WITH_GAPS, want_last_row=True, n_total=n_total if prune else None,
+                   before_end=lambda eng: got.update(row=eng.streamReadLastRow()))
+            dt = time.time() - t0
+            st = al.getStatistics()
+            st["restarts"] = br.restarts
+        finally:
+            al.close()
+        rows[key] = got["row"]
+        out[key] = {"value": float(m) * n / dt / 1e9, "unit": "GCUPS (m*n)", "seconds": dt, "kernel_ms": st["kernel_ms"], "kernel": st["kernel"],
+                    "strip_rows": st["strip_rows"], "restarts": st["restarts"], "pruned_fraction": st["pruned_cells"] / float(m) / n,
+                    "h_last_cell": int(got["row"][-1, 0]), "last_row_sha256": _sha(got["row"])}
+    out["check"] = {"packed_equals_int32": bool(np.array_equal(rows["packed"], rows["int32"])),
+                    "pruned_last_row_is_a_lower_bound": bool(np.all(rows["packed_pruned"] <= rows["packed"])),
+                    "no_restart": out["packed"]["restarts"] == 0 and out["packed_pruned"]["restarts"] == 0}
+    out["check"]["ok"] = all(out["check"].values())
     return out
 
 

@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define MI355SW_ABI_VERSION 4
+#define MI355SW_ABI_VERSION 5
 
 /* M/libmasa/libmasaTypes.hpp:35-41  cell_t {int h; union{int f; int e;};} 8-byte aligned */
 typedef struct { int32_t h; int32_t f; } mi355sw_cell;
@@ -139,6 +139,17 @@ typedef struct {
     double wait_ms;             /* time the strip wavefronts spent waiting for first-column rows that somebody else
                                    delivers (the host, or the previous band's GPU through the column port), average
                                    per wavefront: what a band of a chain loses to its left neighbour              */
+    /* (ABI 5) which kernel did the work -- the reference prints its launch geometry per run (sw_stage1.cpp:440-448,
+     * CUDAligner::printInitialStatistics); a measurement must be able to name the code it measured */
+    int32_t strips_first;       /* mixed-height launches: strips [0, strips_first) are strip_rows tall, the others
+                                   strip_rows_second (one launch, sw_strip_kernel_pk16_mixed); otherwise = strips, 0 */
+    int32_t strip_rows_second;
+    int32_t restarts;           /* reruns on the int32 kernels after an overflow report of the packed one */
+    int32_t reserved_;
+    char kernel[64];            /* the kernel instantiation of the (last) main launch, as the profiler names it without
+                                   its namespace: "sw_strip_kernel_pk16_mixed<12,11,true,true>", "sw_strip_kernel_pk16<16,
+                                   false,false,true>" (rows per half, track, SW, prune), "sw_strip_kernel<8,true,true,true>"
+                                   (rows per lane, SW, profile, track), "sw_batch_kernel_pk16<2,...>" */
 } mi355sw_stats;
 
 /* ---- life cycle: IAligner::initialize/finalize (IAligner.hpp:186,226; X/CUDAligner.cpp:137-174) ---- */

@@ -79,7 +79,9 @@ class Stats(C.Structure):
     _fields_ = [("cells", C.c_int64), ("processed_cells", C.c_int64), ("kernel_ms", C.c_double),
                 ("total_ms", C.c_double), ("kernel_launches", C.c_int32), ("strips", C.c_int32),
                 ("strip_rows", C.c_int32), ("waves", C.c_int32), ("profile_kernel", C.c_int32),
-                ("algorithmic_bytes", C.c_int64), ("pruned_cells", C.c_int64), ("wait_ms", C.c_double)]
+                ("algorithmic_bytes", C.c_int64), ("pruned_cells", C.c_int64), ("wait_ms", C.c_double),
+                ("strips_first", C.c_int32), ("strip_rows_second", C.c_int32), ("restarts", C.c_int32), ("reserved_", C.c_int32),
+                ("kernel", C.c_char * 64)]
 
 
 class StreamParams(C.Structure):
@@ -418,7 +420,9 @@ class MI355Aligner:
     def getStatistics(self):
         s = Stats()
         self._check(self._lib.mi355sw_get_stats(self._h, C.byref(s)), "getStatistics")
-        return {k: getattr(s, k) for k, _ in Stats._fields_}
+        out = {k: getattr(s, k) for k, _ in Stats._fields_}
+        out["kernel"] = out["kernel"].decode()
+        return out
 
     # -- streaming form (column-band driver) ---------------------------------------------------
     def streamBegin(self, partition, recurrence_type=SMITH_WATERMAN, first_row_init_type=INIT_WITH_ZEROES,

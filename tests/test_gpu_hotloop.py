@@ -142,8 +142,10 @@ def test_two_phase_run_with_pruning_locates_the_same_cell(pkg, monkeypatch):
 
 def test_score_only_pass_with_mixed_heights_agrees_with_int32(pkg):
     """the C2 kernel itself (mixed strip heights in one launch, score only, hot loop in every strip) on a shape that
-    engages it -- 2.2 rounds of 1536-row strips -- against the int32 kernels: same best cell"""
-    m, n = 3400000, 70000
+    engages it -- 1.9 rounds of 1536-row strips, wide enough for the cost model to want them (at 70 000 columns, the
+    shape this test had in round 3, it picks 512-row strips and the mixed form never ran) -- against the int32 kernels:
+    same best cell"""
+    m, n = 3000000, 600000
     s0, s1 = pkg.seqgen.related_pair(m, n, cfg=72)
     part = pkg.Partition(0, 0, m, n)
     res = {}
@@ -158,6 +160,7 @@ def test_score_only_pass_with_mixed_heights_agrees_with_int32(pkg):
             al.close()
     assert res[0][0] == res[2][0]
     assert res[0][1]["profile_kernel"] == 2
+    assert res[0][1]["kernel"] == "sw_strip_kernel_pk16_mixed<12,11,true,true>" and res[0][1]["strip_rows_second"] == 1408    # it did engage
 
 
 def _fuzz_wide(k):

@@ -222,8 +222,9 @@ def test_large_roundtrip_properties(pkg, aligner):
 def test_c2_full_size_invariants(pkg, oracle):
     """BASELINE config C2 at its full size (3 M x 3 M, unrelated ACGT, 9e12 cells) -- no oracle can sweep
     that in a test, so the result is pinned through size-independent properties:
-      * three different engines agree bit for bit on (i, j, score): packed kernel with 1536-row strips,
-        packed kernel with 1024-row strips, int32 kernel;
+      * four different engines agree bit for bit on (i, j, score): the kernel bench.py times -- default configuration:
+        1536- and 1408-row strips in ONE launch, which the library reports itself (mi355sw_stats.kernel) --, the packed
+        kernel with 1536-row strips, the packed kernel with 1024-row strips, the int32 kernel;
       * the reported cell is real: the oracle, run on the 600 x 600 window that ends at it (a local
         alignment of that score is far shorter), computes H = score at exactly that corner and nothing
         higher inside the window."""
@@ -231,18 +232,26 @@ def test_c2_full_size_invariants(pkg, oracle):
     s0, s1 = pkg.seqgen.unrelated_pair(m, n, cfg=2)
     part = pkg.Partition(0, 0, m, n)
     results = []
-    for (R, flags, kernel) in ((24, 0, 2), (16, 0, 2), (16, 2, 1)):
+    for (R, flags, kernel) in ((0, 0, 2), (24, 0, 2), (16, 0, 2), (16, 2, 1)):
         al = pkg.MI355Aligner(device=0, rows_per_lane=R, flags=flags)
         try:
             al.setSequences(s0, s1)
             mg = pkg.Stage1Manager(part)
             al.alignPartition(part, mg)
             st = al.getStatistics()
-            assert st["profile_kernel"] == kernel and st["strip_rows"] == 64 * R
+            assert st["profile_kernel"] == kernel and st["restarts"] == 0
+            if R == 0:
+                # what the driver's bench line runs: the mixed-height kernel, a whole number of rounds of strips
+                assert st["kernel"] == "sw_strip_kernel_pk16_mixed<12,11,true,true>", st["kernel"]
+                assert st["strip_rows"] == 1536 and st["strip_rows_second"] == 1408 and st["strips"] % st["waves"] == 0
+                assert st["strips_first"] * 1536 + (st["strips"] - st["strips_first"]) * 1408 >= m
+            else:
+                assert st["strip_rows"] == 64 * R and st["strip_rows_second"] == 0 and st["strips_first"] == st["strips"]
+                assert st["kernel"].startswith("sw_strip_kernel_pk16<%d,true,true,false>" % (R // 2) if kernel == 2 else "sw_strip_kernel<%d,true,true,true>" % R)
             results.append(tuple(mg.getBestScore()))
         finally:
             al.close()
-    assert results[0] == results[1] == results[2]
+    assert results[0] == results[1] == results[2] == results[3]
     i, j, score = results[0]            # 1-based DP coordinates (dispatchScore convention)
     assert 18 <= score <= 30
     W = 600
