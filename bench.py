@@ -127,6 +127,10 @@ def main():
     ap.add_argument("--size", type=int, default=3000000, help="n (and m per GPU) of the synthetic pair")
     ap.add_argument("--rows-per-lane", type=int, default=int(os.environ.get("MI355SW_R", "0")))
     ap.add_argument("--waves", type=int, default=int(os.environ.get("MI355SW_WAVES", "0")))
+    ap.add_argument("--reserve-cus", type=int, default=int(os.environ.get("MI355SW_RESERVE_CUS", "0")),
+                    help="leave this many compute units of every GPU without a strip wavefront (waves = 4 * (CUs - K)): room for "
+                         "somebody else's kernels -- an RCCL send/recv beside the persistent strip kernel, which otherwise owns every "
+                         "SIMD; measured cost: profiles/r04_reserved_cus.json")
     ap.add_argument("--tall", type=int, default=8, help="N > 1: rows per GPU = tall * size (weak scaling)")
     ap.add_argument("--related", action="store_true",
                     help="a RELATED synthetic pair (2 %% substitutions, indels, one inversion) with block pruning on in every "
@@ -185,6 +189,8 @@ def main():
     m = args.size * (1 if world == 1 else args.tall * world)
     s0, s1 = (pkg.seqgen.related_pair if args.related else pkg.seqgen.unrelated_pair)(m, n, cfg=2)
     waves = args.waves
+    if waves == 0 and args.reserve_cus > 0:
+        waves = 4 * max(1, torch.cuda.get_device_properties(local_rank).multi_processor_count - args.reserve_cus)
     if rehearse and waves == 0:
         waves = 1024 // world // 2        # all ranks' strip kernels must be resident on the one GPU together
     # N > 1: strip height from the chain model (bands.rows_per_lane_for_bands)
@@ -223,6 +229,7 @@ def main():
     # (--related: pruning on, every band against the best of the whole chain -- bands.py / include/mi355sw.h share_best)
     runner = BandRunner(al, dist=_Dist() if world > 1 else None, rank=rank, world=world, device=None,
                         segment_rows=1 << 15, transport=comm, prune_blocks=args.related)
+    attach_chain = None                # bands.InProcessChain on rank 0 when the ranks' hipIpc ports fail their check
     if world > 1:
         runner.reduce_best = lambda b, _r=runner: _reduce_cpu(dist, b, world, coll_device)
     comm_note = None
@@ -241,11 +248,47 @@ def main():
                 dist.all_reduce(t, op=dist.ReduceOp.MIN)
                 return int(t.item())
             usable = runner.verify_p2p(min(m, 1 << 20), j0, j1, all_min, budget_s=60.0)
+        if os.environ.get("MI355SW_BENCH_FAIL_IPC") == "1":      # rehearsal of the fall-backs: as if the hipIpc check had failed
+            usable = False
+            runner.p2p_error = "MI355SW_BENCH_FAIL_IPC=1"
         if not usable:
-            comm_note = "p2p unavailable (%s): pinned host columns + gloo instead" % (runner.p2p_error or "a neighbour rank failed")
-            comm = "host"
-            runner.transport = "host"
+            # Second device-side transport before anybody touches host memory: rank 0 drives ALL bands from its one process,
+            # ports attached with hipDeviceEnablePeerAccess (mi355sw_port_attach, bands.InProcessChain) -- no hipIpc handle, no
+            # second process.  Checked like the first: a 1 Mi-row chain must report what one band over all columns reports.
             al.portClose()
+            ipc_error = runner.p2p_error or "a neighbour rank failed"
+            flag = torch.zeros(1, dtype=torch.int32, device=coll_device)
+            attach_error = None
+            if rank == 0 and os.environ.get("MI355SW_BENCH_NO_ATTACH") != "1":
+                try:
+                    from masa_cudalign_amd.bands import InProcessChain
+                    devs = [0] * world if rehearse else list(range(world))
+                    if not rehearse and pkg.engine.load_library().mi355sw_device_count() < world:
+                        raise RuntimeError("rank 0 sees fewer than %d GPUs" % world)
+                    chain_als = [pkg.MI355Aligner(device=d, rows_per_lane=rows_per_lane, waves=waves) for d in devs]
+                    for a2 in chain_als:
+                        a2.setSequences(s0, s1)
+                    attach_chain = InProcessChain(chain_als, prune_blocks=args.related)
+                    mm = min(m, 1 << 20)
+                    got, _ = attach_chain.run(mm, lim, **_chain_kw(args))
+                    want = _single_band(pkg, al, mm, n, args)
+                    if tuple(got) != tuple(want):
+                        raise RuntimeError("attached chain reports %r, one band %r" % (tuple(got), tuple(want)))
+                    flag += 1
+                except Exception as e:                   # noqa: BLE001
+                    attach_error = "%s: %s" % (type(e).__name__, e)
+                    attach_chain = None
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            if int(flag.item()) == 1:
+                comm = "p2p-attach"
+                comm_note = "hipIpc ports unavailable (%s): rank 0 drives all %d bands, ports attached with peer access inside its process" % (ipc_error, world)
+            else:
+                notes = [attach_error] if rank == 0 else [None]
+                dist.broadcast_object_list(notes, src=0, group=p2p_group)
+                comm_note = ("device-to-device ports unavailable -- hipIpc between the ranks: %s; peer access inside rank 0: %s -- "
+                             "pinned host columns + gloo instead" % (ipc_error, notes[0]))
+                comm = "host"
+                runner.transport = "host"
 
     # N > 1: what ONE GPU does with the same number of cells as its share of the chain -- (tall*size) x size, one band,
     # no neighbour -- so that the scaling figure compares like with like (the N = 1 line of this bench is C2, a
@@ -253,17 +296,39 @@ def main():
     single_ref = None
     if world > 1 and not args.no_single_reference:
         if rank == 0:
+            # its own engine, default configuration (the strip height one GPU would pick for this shape, not the chain's),
+            # the same recurrence and pruning as the chain; one untimed run first (buffers, seed pass), then the timed one
             mm = args.size * args.tall
-            t0s = time.time()
-            b1 = BandRunner(al).run(mm, 0, n)
-            dts = time.time() - t0s
-            st1 = al.getStatistics()
-            single_ref = {"workload": "%dx%d on rank 0 alone (one GPU's share of the chain's cells)" % (mm, n),
-                          "gcups": float(mm) * n / dts / 1e9, "seconds": dts, "kernel_ms": st1["kernel_ms"],
-                          "strip_rows": st1["strip_rows"], "best": {"i": b1[0] + 1, "j": b1[1] + 1, "score": b1[2]}}
+            al1 = pkg.MI355Aligner(device=local_rank, waves=waves)
+            try:
+                al1.setSequences(s0, s1)
+                _single_band(pkg, al1, mm, n, args)
+                t0s = time.time()
+                b1 = _single_band(pkg, al1, mm, n, args)
+                dts = time.time() - t0s
+                st1 = al1.getStatistics()
+            finally:
+                al1.close()
+            single_ref = {"workload": "%dx%d on rank 0 alone (one GPU's share of the chain's cells), same recurrence and pruning, the "
+                                      "engine's own strip height, second of two runs" % (mm, n),
+                          "gcups": float(mm) * n / dts / 1e9, "kernel_gcups": float(mm) * n / st1["kernel_ms"] / 1e6, "seconds": dts,
+                          "kernel_ms": st1["kernel_ms"], "strip_rows": st1["strip_rows"], "kernel": st1["kernel"],
+                          "pruned_fraction": st1["pruned_cells"] / float(mm) / n,
+                          "best": {"i": b1[0] + 1, "j": b1[1] + 1, "score": b1[2]}}
         dist.barrier()
 
     def one_step():
+        if comm == "p2p-attach":
+            # rank 0 drives every band (the other ranks wait at the fences); the statistics are band 0's, the slowest
+            # kernel's time in place of its own
+            if rank != 0:
+                return (-1, -1, -INF_), {}
+            best, sts = attach_chain.run(m, lim, **_chain_kw(args))
+            st = dict(sts[0])
+            st["kernel_ms"] = max(s["kernel_ms"] for s in sts)
+            st["pruned_cells"] = sum(s["pruned_cells"] for s in sts)
+            st["bands"] = sts
+            return best, st
         if args.nw:
             # global alignment: gap-initialised borders, nothing tracked, the answer is the last band's last cell
             from masa_cudalign_amd.engine import NEEDLEMAN_WUNSCH, INIT_WITH_GAPS, INF
@@ -283,6 +348,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    INF_ = 999999999
     best = None
     fence()                            # all bands start together: a band's kernel waits a bounded time for its left neighbour
     for _ in range(args.warmup):
@@ -292,9 +358,9 @@ def main():
     kernel_ms, wait_ms, pruned = [], [], []
     for _ in range(args.steps):
         best, st = one_step()
-        kernel_ms.append(st["kernel_ms"])
+        kernel_ms.append(st.get("kernel_ms", 0.0))
         wait_ms.append(st.get("wait_ms", 0.0))
-        pruned.append(st["pruned_cells"])
+        pruned.append(st.get("pruned_cells", 0) if comm != "p2p-attach" or rank != 0 else st["bands"][0]["pruned_cells"])
     fence()
     dt = time.time() - t0
     if world > 1:
@@ -306,6 +372,8 @@ def main():
     if world > 1:
         # who ran what where: one record per rank, gathered over the gloo side group
         prop = torch.cuda.get_device_properties(local_rank)
+        if comm == "p2p-attach" and rank == 0:
+            band_stats = st["bands"]
         mine = {"rank": rank, "device": local_rank, "name": prop.name,
                 "pci_bus_id": getattr(prop, "pci_bus_id", None), "pci_device_id": getattr(prop, "pci_device_id", None),
                 "band_columns": [j0, j1], "kernel_ms": sum(kernel_ms) / len(kernel_ms),
@@ -313,6 +381,10 @@ def main():
                 "pruned_cells": sum(pruned) / len(pruned), "restarts": runner.restarts, "p2p_error": runner.p2p_error}
         ranks = [None] * world
         dist.all_gather_object(ranks, mine, group=p2p_group)
+        if comm == "p2p-attach" and rank == 0:        # every band ran in rank 0's process: its per-band figures
+            for k, r in enumerate(ranks):
+                r.update(kernel_ms=band_stats[k]["kernel_ms"], wait_for_left_neighbour_ms=band_stats[k].get("wait_ms", 0.0),
+                         pruned_cells=band_stats[k]["pruned_cells"], restarts=attach_chain.restarts, driven_by_rank=0)
     if rank == 0:
         cells = float(m) * float(n)
         gcups = cells * args.steps / dt / 1e9
@@ -341,11 +413,12 @@ def main():
                            if args.related else "unrelated random ACGT",
                            "global NW (gap-initialised borders)" if args.nw else "local SW", world, n // world, comm)),
                        "m": m, "n": n, "bands": world, "strip_rows": st["strip_rows"], "waves_per_gpu": st["waves"],
+                       "reserved_cus": args.reserve_cus,
                        "kernel": {2: "pk16", 1: "int32-profile", 0: "int32-generic"}[st["profile_kernel"]],
                        "comm": comm if world > 1 else "none", "comm_note": comm_note,
                        # does the boundary column cross a GPU-to-GPU link?  Only with column ports between different
                        # devices; the host transport (pinned columns + gloo over loopback) and a rehearsal do not
-                       "xgmi": bool(world > 1 and comm == "p2p" and not rehearse),
+                       "xgmi": bool(world > 1 and comm in ("p2p", "p2p-attach") and not rehearse),
                        "collectives": ({"backend": dist.get_backend(), "world": dist.get_world_size()} if world > 1 else None),
                        "ranks": ranks, "same_shape_single_gpu": single_ref,
                        "related_pair": bool(args.related), "recurrence": "NW" if args.nw else "SW",
@@ -388,6 +461,27 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def _chain_kw(args):
+    """recurrence and borders of the chain for bands.InProcessChain.run"""
+    from masa_cudalign_amd.engine import NEEDLEMAN_WUNSCH, SMITH_WATERMAN, INIT_WITH_GAPS, INIT_WITH_ZEROES
+    if args.nw:
+        return dict(recurrence=NEEDLEMAN_WUNSCH, first_row_init_type=INIT_WITH_GAPS, first_col_init_type=INIT_WITH_GAPS)
+    return dict(recurrence=SMITH_WATERMAN, first_row_init_type=INIT_WITH_ZEROES, first_col_init_type=INIT_WITH_ZEROES)
+
+
+def _single_band(pkg, al, m, n, args):
+    """one band over all n columns on one engine, same recurrence / pruning as the chain: (i, j, score) 0-based"""
+    from masa_cudalign_amd.bands import BandRunner
+    from masa_cudalign_amd.engine import NEEDLEMAN_WUNSCH, INIT_WITH_GAPS
+    br = BandRunner(al, prune_blocks=args.related)
+    if not args.nw:
+        return br.run(m, 0, n)
+    got = {}
+    br.run(m, 0, n, recurrence=NEEDLEMAN_WUNSCH, track_best=False, first_row_init_type=INIT_WITH_GAPS, first_col_init_type=INIT_WITH_GAPS,
+           want_last_row=True, before_end=lambda eng: got.update(h=int(eng.streamReadLastRow(col=n - 1, length=1)[0, 0])))
+    return (m - 1, n - 1, got["h"])
 
 
 def target_shape(pkg, device, check=True):
@@ -441,27 +535,29 @@ def c3_shape(pkg, device):
     al = pkg.MI355Aligner(device=device)
     try:
         al.setSequences(s0, s1)
-        for prune in (False, True):
+        for prune in (False, True, "own"):
+            # ("own": the band as a matrix in its own right -- the bound sees only its 1 M columns, nearly everything below
+            #  the alignment goes: runs of skipped slabs and whole skipped strips at C3's height)
             rows = {}
             t0 = time.time()
-            br = BandRunner(al, prune_blocks=prune)
-            best = br.run(m, 0, n, special_row_interval=8 << 20, n_total=n_total,
+            br = BandRunner(al, prune_blocks=bool(prune))
+            best = br.run(m, 0, n, special_row_interval=8 << 20, n_total=n_total if prune != "own" else n,
                           special_row_sink=lambda dp, c0, cells: rows.__setitem__(dp, cells.copy()))
             dt = time.time() - t0
             st = al.getStatistics()
             st["restarts"] = br.restarts
             res[prune] = (best, rows)
-            out["pruned" if prune else "plain"] = {"value": float(m) * n / dt / 1e9, "unit": "GCUPS (m*n)", "seconds": dt, "kernel_ms": st["kernel_ms"],
+            out[{False: "plain", True: "pruned", "own": "pruned_own_extent"}[prune]] = {"value": float(m) * n / dt / 1e9, "unit": "GCUPS (m*n)", "seconds": dt, "kernel_ms": st["kernel_ms"],
                                                    "kernel": st["kernel"], "strip_rows": st["strip_rows"], "restarts": st["restarts"],
                                                    "pruned_fraction": st["pruned_cells"] / float(m) / n,
                                                    "best": {"i": best[0] + 1, "j": best[1] + 1, "score": best[2]}}
     finally:
         al.close()
-    (b0, r0), (b1, r1) = res[False], res[True]
+    (b0, r0), (b1, r1), (b2, r2) = res[False], res[True], res["own"]
     out["special_rows"] = {str(dp): _sha(r0[dp]) for dp in sorted(r0)}
-    lower = all(bool(np.all(r1[dp] <= r0[dp])) for dp in r0)
-    maxima = all(int(r1[dp][:, 0].max()) == int(r0[dp][:, 0].max()) for dp in r0 if dp <= b0[0])
-    out["check"] = {"same_best_cell": tuple(b0) == tuple(b1), "same_rows": sorted(r0) == sorted(r1) and len(r0) >= 4,
+    lower = all(bool(np.all(r1[dp] <= r0[dp])) and bool(np.all(r2[dp] <= r0[dp])) for dp in r0)
+    maxima = all(int(r1[dp][:, 0].max()) == int(r0[dp][:, 0].max()) == int(r2[dp][:, 0].max()) for dp in r0 if dp <= b0[0])
+    out["check"] = {"same_best_cell": tuple(b0) == tuple(b1) == tuple(b2), "same_rows": sorted(r0) == sorted(r1) == sorted(r2) and len(r0) >= 4,
                     "pruned_rows_are_lower_bounds": lower, "row_maxima_above_the_best_cell_intact": maxima}
     out["check"]["ok"] = all(out["check"].values())
     return out

@@ -268,11 +268,24 @@ class BandRunner:
         # before band g's first strip is through anyway, and where bands SHARE a GPU (tests and rehearsals on a
         # one-GPU box) a kernel that sits polling for its neighbour has been seen to keep that neighbour's set-up
         # work (fills, the seed pass) off the GPU for tens of seconds.
+        # The token always travels, whatever happens to this band's own start: 1 = started, 0 = failed (no memory for the
+        # special rows, a port that is not there) -- a band that never hears from its left neighbour would sit in recv
+        # with no kernel running and nothing for the stall watchdog to see, and so would every band to its right.
         if not first and dist is not None:
             import torch
             go = torch.zeros(1, dtype=torch.uint8)
             dist.recv(go, src=self.rank - 1)
-        eng.streamBegin(part, **kw)
+            if int(go[0]) != 1:
+                if not last:
+                    dist.send(torch.zeros(1, dtype=torch.uint8), dst=self.rank + 1)
+                raise RuntimeError("band %d/%d: a band to the left failed to start its kernel" % (self.rank, self.world))
+        try:
+            eng.streamBegin(part, **kw)
+        except BaseException:
+            if not last and dist is not None:
+                import torch
+                dist.send(torch.zeros(1, dtype=torch.uint8), dst=self.rank + 1)
+            raise
         if not last and dist is not None:
             import torch
             dist.send(torch.ones(1, dtype=torch.uint8), dst=self.rank + 1)
@@ -435,6 +448,8 @@ class BandRunner:
                         eng.streamEnd()
                     except AlignerError:
                         pass
+                if bx is not None:           # (it leaves its loop at the next all_reduce in which every band has said stop)
+                    bx.join(timeout=5.0)
                 raise errors[0]
             with lock:
                 try:
@@ -514,6 +529,93 @@ class BandRunner:
         out = [torch.empty_like(t) for _ in range(self.world)]
         self.dist.all_gather(out, t)
         return canonical_best([tuple(int(x) for x in o.tolist()) for o in out])
+
+
+class InProcessChain:
+    """The whole band chain driven by ONE host process: handle k runs band k on GPU `devices[k]`, the boundary columns
+    travel through column ports attached with mi355sw_port_attach -- hipDeviceEnablePeerAccess between the devices of one
+    process, no hipIpc handle and no second process involved.  The streaming calls never block (begin launches the
+    persistent kernel, poll reads pinned words), so one thread serves all bands.
+
+    It is the SECOND device-side transport of bench.py: when the ranks' hipIpc mappings fail their check (probe_p2p /
+    verify_p2p) rank 0 runs the chain this way ("comm": "p2p-attach") before anybody falls back to pinned host columns +
+    gloo; and it is how a single process uses several GPUs (tools, tests).  The reference has no such mode: its bands are
+    forked processes chained by sockets (M/libmasa/libmasa.cpp:540-642).
+    Score passes only (best cell, or H[m][n] of a global alignment): special rows per band are BandRunner's job."""
+
+    def __init__(self, aligners, prune_blocks=False):
+        self.aligners = list(aligners)
+        self.prune_blocks = prune_blocks
+        self.restarts = 0
+        self._rows = 0
+
+    def attach(self, m):
+        """ports of m rows between consecutive bands (made once; a later run of at most m rows resets them)"""
+        als = self.aligners
+        if self._rows >= m:
+            for k in range(1, len(als)):
+                als[k].portReset()
+            return
+        for k in range(1, len(als)):
+            als[k].portCreate(m)
+            als[k - 1].portAttach(als[k])
+        self._rows = m
+
+    def run(self, m, limits, recurrence=SMITH_WATERMAN, first_row_init_type=INIT_WITH_ZEROES, first_col_init_type=INIT_WITH_ZEROES,
+            force_int32=False, poll_sleep=0.0005):
+        """limits = band_limits(n, weights): band k = columns [limits[k], limits[k+1]).  Returns (best, per-band statistics):
+        best = the canonical best cell of the chain (0-based), or for NEEDLEMAN_WUNSCH (m-1, n-1, H[m][n])."""
+        from .engine import AlignerError
+        als, N = self.aligners, len(self.aligners)
+        n = limits[-1]
+        sw = recurrence == SMITH_WATERMAN
+        self.attach(m)
+        for attempt in (0, 1):
+            begun = []
+            try:
+                for k in range(N):                         # left to right: band k+1's kernel starts after band k's
+                    kw = dict(recurrence_type=recurrence, track_best=sw, first_row_init_type=first_row_init_type,
+                              first_row_start_offset=limits[k], last_column_port=k < N - 1, want_last_row=(not sw and k == N - 1),
+                              force_int32=bool(force_int32 or attempt))
+                    if self.prune_blocks:
+                        kw.update(prune_blocks=True, prune_rows=m, prune_cols=n - limits[k], share_best=N > 1)
+                    if k == 0:
+                        kw.update(first_column_init_type=first_col_init_type)
+                    else:
+                        corner = np.array([[0, -INF]], dtype=np.int32)
+                        if first_row_init_type != INIT_WITH_ZEROES:
+                            corner[0, 0] = -2 * limits[k] - (3 if first_row_init_type == 1 else 0)
+                        kw.update(first_column_init_type=INIT_WITH_CUSTOM_DATA, first_column=corner, first_column_port=True)
+                    als[k].streamBegin(Partition(0, limits[k], m, limits[k + 1]), **kw)
+                    begun.append(k)
+                open_ = set(range(N))
+                while open_:
+                    for k in sorted(open_):
+                        _rows, fin = als[k].streamPoll()
+                        if fin:
+                            open_.discard(k)
+                    if open_:
+                        time.sleep(poll_sleep)
+                bests, stats, h_last = [], [], None
+                for k in range(N):
+                    if not sw and k == N - 1:
+                        h_last = int(als[k].streamReadLastRow(col=limits[k + 1] - limits[k] - 1, length=1)[0, 0])
+                    b, _ = als[k].streamEnd()
+                    bests.append(b)
+                    stats.append(als[k].getStatistics())
+                best = canonical_best(bests) if sw else (m - 1, n - 1, h_last)
+                return best, stats
+            except AlignerError as e:
+                for k in begun:                            # stop whatever is running, then the whole chain again on the int32 kernels
+                    for fn in (als[k].streamAbort, als[k].streamEnd):
+                        try:
+                            fn()
+                        except AlignerError:
+                            pass
+                if "EOVERFLOW16" not in str(e) or force_int32 or attempt == 1:
+                    raise
+                self.restarts += 1
+                self.attach(m)
 
 
 def band_stage1(runner, m, j0, j1, work, sra_limit, n_total=None, recurrence=SMITH_WATERMAN,

@@ -403,3 +403,150 @@ def test_wide_bands_with_pruning_against_the_single_partition(pkg):
                 assert np.all(got <= row[1:]), dp
     assert all(res[r]["plain"]["pruned"] == 0 for r in range(world))
     assert sum(res[r]["pruned"]["pruned"] for r in range(world)) > 0.15 * m * n
+
+
+# ---- bands on DISTINCT devices (round 4) -------------------------------------------------------------------------------
+# Everything above runs its bands on cuda:0 -- the test boxes have one GPU -- so no boundary column ever crossed a GPU-to-GPU
+# link in a test.  The tests below are the same chains with band k on device k; they skip themselves where
+# mi355sw_device_count() is smaller than the chain (and are the first thing to run on a multi-GPU node).
+
+def _devices(pkg):
+    return pkg.engine.load_library().mi355sw_device_count()
+
+
+def _worker_devices(rank, world, port, m, n, q, prune):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    import __graft_entry__ as graft
+    pkg = graft.load_package()
+    from masa_cudalign_amd.bands import BandRunner, band_limits
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        s0, s1 = pkg.seqgen.related_pair(m, n, cfg=48)
+        lim = band_limits(n, [1] * world)
+        out = {}
+        for transport in ("p2p", "host"):
+            al = pkg.MI355Aligner(device=rank)                       # band k on GPU k
+            al.setSequences(s0, s1)
+            runner = BandRunner(al, dist=dist, rank=rank, world=world, device=None, segment_rows=4096, transport=transport, prune_blocks=prune)
+            best = runner.run(m, lim[rank], lim[rank + 1], n_total=n, digest_inbound=True)
+            st = al.getStatistics()
+            out[transport] = dict(best=tuple(runner.reduce_best(best)), crc=runner.inbound_crc, pruned=int(st["pruned_cells"]),
+                                  restarts=runner.restarts, kernel=st["kernel"])
+            dist.barrier()
+            al.close()
+        q.put((rank, out))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("prune", [False, True])
+def test_bands_on_distinct_devices_in_separate_processes(pkg, prune):
+    """band k on GPU k, one process per band, ports mapped with hipIpc ACROSS devices (the path bench.py --gpus N takes):
+    the chain's best cell is the single partition's, and every band receives through its port the very column it
+    receives through the host (crc32)"""
+    world = min(_devices(pkg), 4)
+    if world < 2:
+        pytest.skip("needs at least two GPUs (mi355sw_device_count() = %d)" % _devices(pkg))
+    m, n = 200000, 80000 * world
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_devices, args=(r, world, port, m, n, q, prune)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=800) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    s0, s1 = pkg.seqgen.related_pair(m, n, cfg=48)
+    al = pkg.MI355Aligner(device=0, flags=2)
+    try:
+        al.setSequences(s0, s1)
+        part = pkg.Partition(0, 0, m, n)
+        mg = pkg.Stage1Manager(part)
+        al.alignPartition(part, mg)
+        i, j, sc = mg.getBestScore()
+    finally:
+        al.close()
+    for r in range(world):
+        assert res[r]["p2p"]["best"] == res[r]["host"]["best"] == (i - 1, j - 1, sc), (r, res[r])
+        assert res[r]["p2p"]["restarts"] == 0 and res[r]["host"]["restarts"] == 0
+        if r > 0 and not prune:           # (with pruning the two runs may skip different slabs: lower bounds, not the same cells)
+            assert res[r]["p2p"]["crc"] == res[r]["host"]["crc"], r
+    if prune:
+        assert sum(res[r]["p2p"]["pruned"] for r in range(world)) > 0
+
+
+@pytest.mark.parametrize("recurrence", ["sw", "nw"])
+def test_chain_on_distinct_devices_in_one_process(pkg, recurrence):
+    """bands.InProcessChain: band k on GPU k, all driven by this process, ports attached with peer access
+    (mi355sw_port_attach -> hipDeviceEnablePeerAccess; bench.py's "p2p-attach" transport).  Result = one band over all
+    columns on GPU 0."""
+    from masa_cudalign_amd.bands import InProcessChain, BandRunner, band_limits
+    world = min(_devices(pkg), 4)
+    if world < 2:
+        pytest.skip("needs at least two GPUs (mi355sw_device_count() = %d)" % _devices(pkg))
+    m, n = 300000, 100000 * world
+    s0, s1 = pkg.seqgen.related_pair(m, n, cfg=49)
+    als = [pkg.MI355Aligner(device=k) for k in range(world)]
+    try:
+        for a in als:
+            a.setSequences(s0, s1)
+        kw = dict(recurrence=pkg.NEEDLEMAN_WUNSCH, first_row_init_type=pkg.INIT_WITH_GAPS, first_col_init_type=pkg.INIT_WITH_GAPS) if recurrence == "nw" else {}
+        for prune in (False, True):
+            chain = InProcessChain(als, prune_blocks=prune)
+            best, stats = chain.run(m, band_limits(n, [1] * world), **kw)
+            assert chain.restarts == 0
+            if recurrence == "sw":
+                want = BandRunner(als[0]).run(m, 0, n)
+            else:
+                got = {}
+                BandRunner(als[0]).run(m, 0, n, recurrence=pkg.NEEDLEMAN_WUNSCH, track_best=False, first_row_init_type=pkg.INIT_WITH_GAPS,
+                                       first_col_init_type=pkg.INIT_WITH_GAPS, want_last_row=True,
+                                       before_end=lambda eng: got.update(h=int(eng.streamReadLastRow(col=n - 1, length=1)[0, 0])))
+                want = (m - 1, n - 1, got["h"])
+            assert tuple(best) == tuple(want), (prune, best, want)
+            if prune:
+                assert sum(s["pruned_cells"] for s in stats) > 0
+    finally:
+        for a in als:
+            a.close()
+
+
+@pytest.mark.parametrize("recurrence", ["sw", "nw"])
+def test_chain_in_one_process_on_one_device(pkg, recurrence):
+    """the same InProcessChain with all four bands on cuda:0 (what a one-GPU box can run of it: the driver, the ports, the
+    concurrent kernels -- 128 wavefronts each so that all four are resident): local and global, with and without pruning,
+    against one band over all columns"""
+    from masa_cudalign_amd.bands import InProcessChain, BandRunner, band_limits
+    world, m, n = 4, 160000, 240000
+    s0, s1 = pkg.seqgen.related_pair(m, n, cfg=50)
+    als = [pkg.MI355Aligner(device=0, waves=128, rows_per_lane=8) for _ in range(world)]
+    ref = pkg.MI355Aligner(device=0)
+    try:
+        for a in als + [ref]:
+            a.setSequences(s0, s1)
+        kw = dict(recurrence=pkg.NEEDLEMAN_WUNSCH, first_row_init_type=pkg.INIT_WITH_GAPS, first_col_init_type=pkg.INIT_WITH_GAPS) if recurrence == "nw" else {}
+        if recurrence == "sw":
+            want = BandRunner(ref).run(m, 0, n)
+        else:
+            got = {}
+            BandRunner(ref).run(m, 0, n, recurrence=pkg.NEEDLEMAN_WUNSCH, track_best=False, first_row_init_type=pkg.INIT_WITH_GAPS,
+                                first_col_init_type=pkg.INIT_WITH_GAPS, want_last_row=True,
+                                before_end=lambda eng: got.update(h=int(eng.streamReadLastRow(col=n - 1, length=1)[0, 0])))
+            want = (m - 1, n - 1, got["h"])
+        for prune in (False, True):
+            chain = InProcessChain(als, prune_blocks=prune)
+            for rep in range(2):                           # the second run re-uses (resets) the attached ports
+                best, stats = chain.run(m, band_limits(n, [1] * world), **kw)
+                assert tuple(best) == tuple(want), (prune, rep, best, want)
+            assert chain.restarts == 0 and all(s["profile_kernel"] == 2 for s in stats)
+            if prune:
+                assert sum(s["pruned_cells"] for s in stats) > 0.2 * m * n
+    finally:
+        for a in als + [ref]:
+            a.close()

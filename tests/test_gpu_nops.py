@@ -1,0 +1,88 @@
+"""GPU (-m gpu): the library as shipped (csrc/strip_pk_nops.py removes the `s_nop 0` hipcc's hazard recognizer puts behind a
+packed instruction whose result the next packed instruction reads) against the SAME sources built with the compiler's
+wait states left in (`make -C masa-cudalign_amd/csrc keepnops` -> libmi355sw_keepnops.so).
+
+The rule that inserts them (GCNHazardRecognizer::checkVALUHazards, hasDstSelForwardingHazard(), getDstSelForwardingOperand:
+src0_modifiers & DST_OP_SEL -- the bit a VOP3P instruction uses for op_sel_hi[0]) is documented in strip_pk_nops.py and
+probed in profiles/r04_pk_nop_hazard_probe.txt: a false positive for instructions that write all 32 bits.  This test is the
+other half of the argument: every observable of both builds, side by side -- C2 at its full size (the kernel bench.py
+times), and seeded cases of every packed family (local / global / semi-global, tracking, pruning, special rows, strip heights).
+
+Each build runs in a child process of its own (a process loads ONE libmi355sw through MI355SW_LIB)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+KEEP = os.path.join(ROOT, "masa-cudalign_amd", "libmi355sw_keepnops.so")
+
+CHILD = r"""
+import hashlib, json, os, sys
+import numpy as np
+sys.path.insert(0, %(root)r)
+import __graft_entry__ as graft
+pkg = graft.load_package()
+EDGE = {0: pkg.AT_ANYWHERE, 1: pkg.AT_SEQUENCE_1, 2: pkg.AT_SEQUENCE_2, 3: pkg.AT_SEQUENCE_1_OR_2, 4: pkg.AT_SEQUENCE_1_AND_2}
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a, dtype=np.int32).tobytes()).hexdigest()
+out = {"library": pkg.engine.LIB_PATH, "build_id": pkg.engine.library_build_id(), "cases": []}
+def one(m, n, kind, R, start, end, prune, interval, cfg):
+    s0, s1 = (pkg.seqgen.related_pair if kind else pkg.seqgen.unrelated_pair)(m, n, cfg=cfg)
+    al = pkg.MI355Aligner(device=0, rows_per_lane=R)
+    try:
+        al.setSequences(s0, s1)
+        part = pkg.Partition(0, 0, m, n)
+        mg = pkg.Stage1Manager(part, alignment_start=EDGE[start], alignment_end=EDGE[end], special_row_interval=interval,
+                               keep_last_row=True, keep_last_column=True, block_pruning=prune)
+        al.alignPartition(part, mg)
+        st = al.getStatistics()
+        rec = {"shape": [m, n, kind, R, start, end, prune, interval], "best": list(mg.getBestScore()), "kernel": st["kernel"],
+               "restarts": st["restarts"], "pruned_cells": st["pruned_cells"], "last_row": sha(mg.lastRow()), "last_col": sha(mg.lastColumn()),
+               "special": {str(i): sha(mg.specialRow(i)) for i in sorted(mg.special_rows)}}
+        out["cases"].append(rec)
+    finally:
+        al.close()
+# C2 at full size: what bench.py times (default configuration: the mixed-height kernel)
+one(3000000, 3000000, 0, 0, 0, 0, False, 0, 2)
+rng = np.random.default_rng(20261003)
+for k in range(32):
+    m = int(rng.integers(3000, 120000)); n = int(rng.integers(3000, 120000))
+    start, end = [(0, 0), (0, 0), (4, 4), (4, 4), (1, 3), (2, 2)][int(rng.integers(0, 6))]
+    R = int(rng.choice([0, 4, 8, 12, 16, 24, 32]))
+    prune = bool(rng.integers(0, 2)) and (start, end) in ((0, 0), (4, 4))
+    one(m, n, int(rng.integers(0, 2)), R, start, end, prune, 8192 if rng.random() < 0.5 else 0, 900 + k)
+print(json.dumps(out))
+"""
+
+
+def _run(lib):
+    env = dict(os.environ)
+    if lib:
+        env["MI355SW_LIB"] = lib
+    else:
+        env.pop("MI355SW_LIB", None)
+    p = subprocess.run([sys.executable, "-c", CHILD % {"root": ROOT}], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900, env=env)
+    assert p.returncode == 0, p.stderr.decode(errors="replace")[-3000:]
+    return json.loads([ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")][-1])
+
+
+@pytest.mark.timeout(1800)
+def test_stripped_and_unstripped_builds_agree_on_every_output():
+    if not os.path.exists(KEEP):
+        pytest.fail("libmi355sw_keepnops.so is not built (make -C masa-cudalign_amd/csrc keepnops; __graft_entry__.build() does it)")
+    a, b = _run(None), _run(KEEP)
+    assert a["library"] != b["library"] and b["library"] == KEEP
+    assert a["build_id"] == b["build_id"]                    # the same sources
+    assert len(a["cases"]) == len(b["cases"]) == 33
+    for x, y in zip(a["cases"], b["cases"]):
+        assert x == y, (x, y)
+    assert a["cases"][0]["kernel"] == "sw_strip_kernel_pk16_mixed<12,11,true,true>"
+    assert all(c["restarts"] == 0 for c in a["cases"])
+    kinds = {c["kernel"].split("<")[0] for c in a["cases"]}
+    assert "sw_strip_kernel_pk16" in kinds and sum(c["pruned_cells"] > 0 for c in a["cases"]) >= 3
