@@ -225,7 +225,7 @@ def main():
         ReduceOp = dist.ReduceOp
 
     # block pruning is left off: C2 is an unrelated pair, on which the reference's (default-on) pruning
-    # prunes nothing either, and the engine's kernel without the skip path is the faster one
+    # prunes nothing either, and the engine's kernel without the skip path is the faster one (block pruning)
     # (--related: pruning on, every band against the best of the whole chain -- bands.py / include/mi355sw.h share_best)
     runner = BandRunner(al, dist=_Dist() if world > 1 else None, rank=rank, world=world, device=None,
                         segment_rows=1 << 15, transport=comm, prune_blocks=args.related)

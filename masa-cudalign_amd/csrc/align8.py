@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Keep every 8-byte gfx950 instruction 8-byte aligned.
 
-Measured on MI355X (tools/micro_fetch.hip): with one wavefront per SIMD an 8-byte
+Measured on MI355X (tools/micro_fetch.hip, docs/NOTEBOOK_r1-r3.md section 5): with one wavefront per SIMD an 8-byte
 instruction that starts at an address = 4 (mod 8) costs about one extra cycle to fetch/decode.  The packed
 strip kernel is ~90 % 8-byte encodings (VOP3P), so whether its hot loop runs at 1.69 s or 1.91 s on the 3M x 3M
 case depended on the parity of the 4-byte instructions in front of it, i.e. on unrelated edits.  This pass takes

@@ -104,9 +104,10 @@ def main():
             odd.append((i + 1, ins[k - 1][1], ins[k + 1][1]))
     open(sys.argv[2], "w").write("\n".join(l for i, l in enumerate(lines) if i not in drop))
     sys.stderr.write("strip_pk_nops: %s: %d of the compiler's s_nop 0 behind packed instructions removed, %d kept (their successor "
-                     "does not read the packed result)\n" % (sys.argv[1], len(drop), len(odd)))
-    for ln, a, b in odd[:8]:
-        sys.stderr.write("strip_pk_nops:   kept line %d: %s | s_nop 0 | %s\n" % (ln, a, b))
+                     "is not a packed instruction reading the result)\n" % (sys.argv[1], len(drop), len(odd)))
+    if "-v" in sys.argv[3:]:
+        for ln, a, b in odd:
+            sys.stderr.write("strip_pk_nops:   kept line %d: %s | s_nop 0 | %s\n" % (ln, a, b))
 
 
 if __name__ == "__main__":

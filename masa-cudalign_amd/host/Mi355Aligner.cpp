@@ -207,7 +207,14 @@ int32_t Mi355Aligner::cbLastRow(void* u) { return SELF->mustDispatchLastRow() ? 
 int32_t Mi355Aligner::cbLastColumn(void* u) { return SELF->mustDispatchLastColumn() ? 1 : 0; }
 int32_t Mi355Aligner::cbSpecialRows(void* u) { return SELF->mustDispatchSpecialRows() ? 1 : 0; }
 int32_t Mi355Aligner::cbScores(void* u) { return SELF->mustDispatchScores() ? 1 : 0; }
-int32_t Mi355Aligner::cbPrune(void* u) { return SELF->mustPruneBlocks() ? 1 : 0; }
+// --prune-global: MASA-Core's stage 1 switches pruning off unless the alignment may end anywhere (sw_stage1.cpp:219-225) although
+// the bound for a global alignment exists (AbstractBlockPruning.cpp:92-109).  The engine has it; it is offered for the
+// partitions whose score is read from the last cell -- never for stages 2 and 3, whose partitions end at a goal
+// (they want scores or a last column, and the engine ignores the request then).
+int32_t Mi355Aligner::cbPrune(void* u) {
+    if (SELF->mustPruneBlocks()) return 1;
+    return (SELF->params->getPruneGlobal() && SELF->getRecurrenceType() == NEEDLEMAN_WUNSCH && SELF->mustDispatchLastCell()) ? 1 : 0;
+}
 #undef SELF
 
 void Mi355Aligner::clearStatistics() { statCells = 0; statKernelMs = 0; statPartitions = 0; statPruned = 0; }

@@ -25,6 +25,10 @@
 --block-columns=W       Also report the best score of every block of the grid\n\
                            (strip x W columns), as MASA-Core's --dump-blocks wants them;\n\
                            needs --strip-rows=256, 512 or 1024 and costs a second sweep.\n\
+--prune-global          Block pruning for GLOBAL alignments as well (--alignment-edges=++):\n\
+                           MASA-Core's stage 1 only asks for pruning when the alignment may end\n\
+                           anywhere; with this option the engine also prunes whenever the score is\n\
+                           read from the last cell, against a lower bound of that cell.\n\
 "
 
 #define ARG_GPU        0x1001
@@ -32,6 +36,7 @@
 #define ARG_BLOCKS     0x1003
 #define ARG_STRIP_ROWS 0x1004
 #define ARG_BLOCK_COLUMNS 0x1005
+#define ARG_PRUNE_GLOBAL 0x1006
 
 static struct option long_options[] = {
     {"gpu",        required_argument, 0, ARG_GPU},
@@ -39,10 +44,11 @@ static struct option long_options[] = {
     {"blocks",     required_argument, 0, ARG_BLOCKS},
     {"strip-rows", required_argument, 0, ARG_STRIP_ROWS},
     {"block-columns", required_argument, 0, ARG_BLOCK_COLUMNS},
+    {"prune-global", no_argument, 0, ARG_PRUNE_GLOBAL},
     {0, 0, 0, 0}
 };
 
-Mi355AlignerParameters::Mi355AlignerParameters() : gpu(MI355_DETECT_FASTEST_GPU), waves(0), stripRows(0), blockColumns(0) {}
+Mi355AlignerParameters::Mi355AlignerParameters() : gpu(MI355_DETECT_FASTEST_GPU), waves(0), stripRows(0), blockColumns(0), pruneGlobal(0) {}
 Mi355AlignerParameters::~Mi355AlignerParameters() {}
 
 void Mi355AlignerParameters::printUsage() const {
@@ -148,6 +154,9 @@ int Mi355AlignerParameters::processArgument(int argc, char** argv) {
             setLastError("--block-columns needs a positive number of columns.");
             return -1;
         }
+        break;
+    case ARG_PRUNE_GLOBAL:
+        pruneGlobal = 1;
         break;
     default:
         return ret;

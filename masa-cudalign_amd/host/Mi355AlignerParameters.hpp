@@ -22,12 +22,13 @@ public:
     int getWaves() const { return waves; }            /* --blocks: strip wavefronts per launch, 0 = one per SIMD */
     int getStripRows() const { return stripRows; }    /* --strip-rows: 256..2048, 0 = cost model */
     int getBlockColumns() const { return blockColumns; }   /* --block-columns: width of the blocks whose scores are dispatched, 0 = none */
+    int getPruneGlobal() const { return pruneGlobal; }     /* --prune-global: block pruning of partitions whose goal is the last cell */
     static void printGPUDevices(FILE* file);          /* --list-gpus (X/cuda_util.cpp:191-230) */
     static int fastestGPU();                          /* X/cuda_util.cpp:238-287: largest CUs x clock */
     static int deviceWeights(int* weights, int max);  /* X/cuda_util.cpp:191-257: per-GPU weights, asked from a child process */
 
 private:
-    int gpu, waves, stripRows, blockColumns;
+    int gpu, waves, stripRows, blockColumns, pruneGlobal;
 };
 
 #endif

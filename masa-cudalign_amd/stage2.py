@@ -126,9 +126,17 @@ def stage2(aligner, seq0, seq1, work, alignment_start=AT_ANYWHERE, sra_limit=0, 
     # first strip's sweep plus one hop per strip down to the goal row, and 512-row strips halve that against the 2048-row
     # strips the engine's cost model picks for a full sweep of such a shape (mi355sw_set_rows_per_lane).  Only when the
     # caller left the height to the engine.
+    # Round 4: ... and the height follows the partition.  The goal lies about as many rows down as the partition is wide (the
+    # alignment runs along the diagonal), and everything the strips of a SECOND round of wavefronts would do comes a whole
+    # sweep later: the height is the smallest whose strips reach that row within the first round of 1024 wavefronts
+    # (heights that divide 8192 only: the special rows this stage stores for stage 3 stay on CUDAlign's grid).
     short_strips = hasattr(aligner, "setRowsPerLane") and aligner.getRowsPerLane() == 0
-    if short_strips:
-        aligner.setRowsPerLane(8)
+
+    def strip_height_for(width):
+        for R in (8, 16, 32):
+            if width * 1.1 <= 1024 * 64 * R:
+                return R
+        return 32
     try:
         while crossing and part1 is not None:
             col_reader, row_reader = part1.first_column_reader, part1.first_row_reader
@@ -151,6 +159,8 @@ def stage2(aligner, seq0, seq1, work, alignment_start=AT_ANYWHERE, sra_limit=0, 
                     else:
                         mgr.setLastRowReader(None)
                     c1 = Crosspoint(len_v - part1.j0, len_h - part1.get_reading_row())
+                    if short_strips:
+                        aligner.setRowsPerLane(strip_height_for(c1.j - cp.j))
                     cp = find_next_crosspoint(mgr, area2, cp, c1, alignment_start)
                     partitions += 1
                     out.write(cp)

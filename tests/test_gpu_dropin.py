@@ -132,6 +132,27 @@ def test_full_pipeline_with_block_pruning_biting(pkg, oracle):
     assert sorted(got) == sorted(int(k) for k in case["special_rows"] if int(k) < case["m"])
 
 
+def test_global_pipeline_with_pruning_through_masa_core(pkg, oracle):
+    """--alignment-edges=++ (a global alignment) through MASA-Core's own stages 1-6 on the engine.  MASA-Core's stage 1 never
+    asks for pruning then (sw_stage1.cpp:219-225); the extension's --prune-global makes the engine prune the partitions
+    whose score is read from the last cell (AbstractBlockPruning.cpp:92-109, per slab).  More than a quarter of the
+    matrix is skipped in stage 1, and MASA-Core's stages 2-6 on top of the lower-bound special rows recover the
+    reference's crosspoints and print its alignment, byte for byte; without the option nothing is skipped."""
+    case = [c for c in G["cases"] if c["name"] == "full_pipeline_global_60000x50000_b8192"][0]
+    for extra, want_pruning in ((["--prune-global"], True), ([], False)):
+        out = _run(pkg, oracle, case["seq"], ["--edges=++", "--disk-size=4M", "--strip-rows=1024"] + extra)
+        assert list(out["best"]) == case["best"]
+        stats = out["statistics"]["statistics_01.00"]
+        pruned = [int(ln.split(":")[1]) for ln in stats.splitlines() if ln.startswith("Pruned cells:")]
+        assert pruned, stats[-600:]
+        if want_pruning:
+            assert pruned[0] > 0.25 * case["m"] * case["n"], stats[-600:]
+        else:
+            assert pruned[0] == 0
+        assert out.get("crosspoints_2") == [tuple(x) for x in case["crosspoints_2"]]
+        assert hashlib.sha256(out["alignment_txt"]).hexdigest() == case["alignment_txt_sha256"]
+
+
 def _run_forked(pkg, seq, args):
     from oracle.binding import _write_fasta, read_ref_work
     s0, s1 = make_pair(pkg, seq)

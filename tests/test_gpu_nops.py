@@ -81,7 +81,14 @@ def test_stripped_and_unstripped_builds_agree_on_every_output():
     assert a["build_id"] == b["build_id"]                    # the same sources
     assert len(a["cases"]) == len(b["cases"]) == 33
     for x, y in zip(a["cases"], b["cases"]):
-        assert x == y, (x, y)
+        if x["shape"][6]:
+            # block pruning: WHICH slabs go depends on when the running best reaches a wavefront -- run to run, of one
+            # library as well -- so the skipped count and the lower-bound cells off the optimal paths are not comparable;
+            # the best cell and the kernel are
+            assert (x["shape"], x["best"], x["kernel"], x["restarts"]) == (y["shape"], y["best"], y["kernel"], y["restarts"]), (x, y)
+            assert (x["pruned_cells"] > 0) == (y["pruned_cells"] > 0)
+        else:
+            assert x == y, (x, y)
     assert a["cases"][0]["kernel"] == "sw_strip_kernel_pk16_mixed<12,11,true,true>"
     assert all(c["restarts"] == 0 for c in a["cases"])
     kinds = {c["kernel"].split("<")[0] for c in a["cases"]}

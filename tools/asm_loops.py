@@ -2,7 +2,7 @@
 """tools/asm_loops.py dev.al.s FUNCTION_SUBSTRING: the loops of one function of an assembled kernel file (hipcc_aligned.sh
 with ALIGN8_KEEP=1 keeps dev.al.s): for every backward branch, the instruction mix of the blocks between its target and
 itself -- how the 64-step chunk loops and the code between them are really made up (VALU by class, LDS, waits, nops,
-branches).  Used to attribute the chunk-boundary and front-end cost of the strip kernel."""
+branches).  Used to attribute the chunk-boundary and front-end cost of the strip kernel (docs/NOTEBOOK_r1-r3.md 4.3)."""
 import collections
 import re
 import sys

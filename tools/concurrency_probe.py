@@ -1,5 +1,5 @@
 """Do two persistent strip kernels of ONE process (two engine handles = two high-priority streams) run at the same
-time on the GPU?  (Precondition of the mixed-strip-height plan in DESIGN.md section 8.)
+time on the GPU?  (Precondition of the mixed-strip-height plan in docs/NOTEBOOK_r1-r3.md section 8.)
 python tools/concurrency_probe.py"""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

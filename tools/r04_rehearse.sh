@@ -22,3 +22,7 @@ run 4 n4_nw --nw
 run 4 n4_nw_related --nw --related
 run 8 n8_nw_related --nw --related
 MI355SW_BENCH_COMM=host run 4 n4_nw_related_host --nw --related
+# the fall-back transports: as if the hipIpc check had failed (p2p-attach), and with the in-process chain refused too (host)
+MI355SW_BENCH_FAIL_IPC=1 run 4 n4_attach
+MI355SW_BENCH_FAIL_IPC=1 run 4 n4_attach_nw_related --nw --related
+MI355SW_BENCH_FAIL_IPC=1 MI355SW_BENCH_NO_ATTACH=1 run 4 n4_host_after_both_failed --related
