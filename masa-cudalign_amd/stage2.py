@@ -129,14 +129,15 @@ def stage2(aligner, seq0, seq1, work, alignment_start=AT_ANYWHERE, sra_limit=0, 
     # Round 4: ... and the height follows the partition.  The goal lies about as many rows down as the partition is wide (the
     # alignment runs along the diagonal), and everything the strips of a SECOND round of wavefronts would do comes a whole
     # sweep later: the height is the smallest whose strips reach that row within the first round of 1024 wavefronts
-    # (48 M x 46 M, 700 k-column partitions: 768 rows -- 912 strips down to the goal row, one round -- instead of 512 rows
-    #  and 1367 strips, a third of them a whole sweep late.  Below 476 k columns 512 rows as before.  The special rows this
-    #  stage stores for stage 3 then sit on multiples of 768 rows; they are this pipeline's own, stage 3 reads their
-    #  positions from the files.)
+    # (48 M x 46 M, 700 k-column partitions: 1024 rows -- 684 strips down to the goal row, one round -- instead of 512 rows
+    #  and 1367 strips, a third of them a whole sweep late; below 476 k columns 512 rows as before.  Only heights that
+    #  divide 8192: the special rows this stage stores for stage 3 then sit where MASA-Core's own stage 2 on the engine
+    #  puts them, and so do the crosspoints of stage 3 -- 768-row strips were 10 % faster at C3 and gave another, equally
+    #  optimal alignment text.)
     short_strips = hasattr(aligner, "setRowsPerLane") and aligner.getRowsPerLane() == 0
 
     def strip_height_for(width):
-        for R in (8, 12, 16, 24, 32):
+        for R in (8, 16, 32):
             if width * 1.1 <= 1024 * 64 * R:
                 return R
         return 32
