@@ -78,6 +78,10 @@ typedef struct {
 } mi355sw_config;
 #define MI355SW_F_FORCE_GENERIC_COMPARE 1   /* raw byte compare kernels even if a profile fits */
 #define MI355SW_F_FORCE_INT32 2             /* never use the packed 16-bit SW kernel */
+#define MI355SW_F_NO_DIAGONAL_SEED 4        /* block pruning without the diagonal seed pass (see mi355sw_stats.seed_ms): the
+                                               bound then only grows with what the sweep itself finds, as in the reference.
+                                               For callers that want SEVERAL alignments (--max-alignments > 1): a strong
+                                               first bound prunes the weaker ones away sooner than the reference's would. */
 
 /* aligner_capabilities_t, M/libmasa/capabilities.hpp:59-225 (same fields, int32 instead of bool) */
 typedef struct {
@@ -146,6 +150,9 @@ typedef struct {
     int32_t strip_rows_second;
     int32_t restarts;           /* reruns on the int32 kernels after an overflow report of the packed one */
     int32_t reserved_;
+    double seed_ms;             /* wall time of the diagonal seed pass that gave a pruning run of a large matrix its first
+                                   bound (0: none ran): a staircase of tiles along the diagonal, swept before the main
+                                   launch; the score it finds is a real alignment's, so the bound is valid whatever it is */
     char kernel[64];            /* the kernel instantiation of the (last) main launch, as the profiler names it without
                                    its namespace: "sw_strip_kernel_pk16_mixed<12,11,true,true>", "sw_strip_kernel_pk16<16,
                                    false,false,true>" (rows per half, track, SW, prune), "sw_strip_kernel<8,true,true,true>"
@@ -268,11 +275,14 @@ int mi355sw_stream_read_special_row(mi355sw_handle* h, int32_t k, int32_t* dp_ro
 int mi355sw_stream_read_last_row(mi355sw_handle* h, mi355sw_cell* cells, int32_t col, int32_t len);
 int mi355sw_stream_abort(mi355sw_handle* h);
 /* share_best streams: `score` is the score of an alignment that exists somewhere in the super-partition (found by
- * another band, another node, a previous run): the running kernel folds it into its pruning bound at its next strip
- * hand-over.  Lower bounds only -- a value no alignment reaches would prune the optimum away. */
+ * another band, another node, a previous run) -- for a GLOBAL alignment (NEEDLEMAN_WUNSCH with prune_blocks): a lower
+ * bound of the score in the super-partition's last cell, e.g. the score of any global alignment of the two sequences
+ * somebody has computed: the running kernel folds it into its pruning bound at its next strip hand-over.  Lower bounds
+ * only -- a value no alignment reaches would prune the optimum away. */
 int mi355sw_stream_best_hint(mi355sw_handle* h, int32_t score);
-/* share_best streams: the best score the kernel knew at its last strip hand-over (its own cells and every hint it
- * received; -MI355SW_INF before the first).  May be called from any thread while the stream runs. */
+/* share_best streams: the best score (global alignments: the best lower bound of the last cell's score) the kernel knew
+ * at its last strip hand-over -- its own cells and every hint it received; -MI355SW_INF before the first.  May be called
+ * from any thread while the stream runs. */
 int mi355sw_stream_running_best(mi355sw_handle* h, int32_t* score);
 /* waits for the kernel; best = canonical (max score, min i, min j), sequence-relative 0-based cell */
 int mi355sw_stream_end(mi355sw_handle* h, mi355sw_score* best, int32_t* n_special_rows);

@@ -81,7 +81,7 @@ class Stats(C.Structure):
                 ("strip_rows", C.c_int32), ("waves", C.c_int32), ("profile_kernel", C.c_int32),
                 ("algorithmic_bytes", C.c_int64), ("pruned_cells", C.c_int64), ("wait_ms", C.c_double),
                 ("strips_first", C.c_int32), ("strip_rows_second", C.c_int32), ("restarts", C.c_int32), ("reserved_", C.c_int32),
-                ("kernel", C.c_char * 64)]
+                ("seed_ms", C.c_double), ("kernel", C.c_char * 64)]
 
 
 class StreamParams(C.Structure):

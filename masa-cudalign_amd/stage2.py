@@ -126,21 +126,13 @@ def stage2(aligner, seq0, seq1, work, alignment_start=AT_ANYWHERE, sra_limit=0, 
     # first strip's sweep plus one hop per strip down to the goal row, and 512-row strips halve that against the 2048-row
     # strips the engine's cost model picks for a full sweep of such a shape (mi355sw_set_rows_per_lane).  Only when the
     # caller left the height to the engine.
-    # Round 4: ... and the height follows the partition.  The goal lies about as many rows down as the partition is wide (the
-    # alignment runs along the diagonal), and everything the strips of a SECOND round of wavefronts would do comes a whole
-    # sweep later: the height is the smallest whose strips reach that row within the first round of 1024 wavefronts
-    # (48 M x 46 M, 700 k-column partitions: 1024 rows -- 684 strips down to the goal row, one round -- instead of 512 rows
-    #  and 1367 strips, a third of them a whole sweep late; below 476 k columns 512 rows as before.  Only heights that
-    #  divide 8192: the special rows this stage stores for stage 3 then sit where MASA-Core's own stage 2 on the engine
-    #  puts them, and so do the crosspoints of stage 3 -- 768-row strips were 10 % faster at C3 and gave another, equally
-    #  optimal alignment text.)
+    # (Round 4 tried heights that follow the partition's width -- the goal lies about as many rows down as the partition is
+    #  wide, and the strips of a second round of wavefronts come a whole sweep late.  C3, 700 k-column partitions: 768-row
+    #  strips 13.1 s against 14.8 s, but the special rows this stage stores for stage 3 then leave CUDAlign's 8192-row grid
+    #  and stage 3 picks another, equally optimal alignment; 1024-row strips, which keep the grid, were slower: 16.8 s.)
     short_strips = hasattr(aligner, "setRowsPerLane") and aligner.getRowsPerLane() == 0
-
-    def strip_height_for(width):
-        for R in (8, 16, 32):
-            if width * 1.1 <= 1024 * 64 * R:
-                return R
-        return 32
+    if short_strips:
+        aligner.setRowsPerLane(8)
     try:
         while crossing and part1 is not None:
             col_reader, row_reader = part1.first_column_reader, part1.first_row_reader
@@ -163,8 +155,6 @@ def stage2(aligner, seq0, seq1, work, alignment_start=AT_ANYWHERE, sra_limit=0, 
                     else:
                         mgr.setLastRowReader(None)
                     c1 = Crosspoint(len_v - part1.j0, len_h - part1.get_reading_row())
-                    if short_strips:
-                        aligner.setRowsPerLane(strip_height_for(c1.j - cp.j))
                     cp = find_next_crosspoint(mgr, area2, cp, c1, alignment_start)
                     partitions += 1
                     out.write(cp)

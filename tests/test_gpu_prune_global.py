@@ -254,3 +254,48 @@ def test_local_pruning_far_above_the_16_bit_window(pkg):
         assert np.all(y <= x) and np.all(y[1:, 0] >= 0), i
         if i <= a.getBestScore()[0]:
             assert y[:, 0].max() == x[:, 0].max() and int(y[:, 0].argmax()) == int(x[:, 0].argmax()), i
+
+
+def test_diagonal_seed_gives_the_same_answers_and_prunes_more(pkg, monkeypatch):
+    """5 M x 4.5 M related pair: a pruning run of a large matrix gets its first bound from a staircase of tiles along the
+    diagonal (runtime.cpp::diagonal_seed; the reference seeds its bound with the best of a resumed run or of the other
+    nodes, sw_stage1.cpp:210-217, AlignerPool).  The seed is the score of a real alignment, so nothing may change but the
+    amount of work: same best cell (local) / same H[m][n] (global) as without the seed and as without pruning, special
+    rows lower bounds of the unpruned ones with the row maxima intact above the best cell, more cells skipped."""
+    m, n = 5000000, 4500000
+    s0, s1 = pkg.seqgen.related_pair(m, n, cfg=37)
+    part = pkg.Partition(0, 0, m, n)
+    al = pkg.MI355Aligner(device=0)
+    try:
+        al.setSequences(s0, s1)
+        for edge in (pkg.AT_ANYWHERE, pkg.AT_SEQUENCE_1_AND_2):
+            res = {}
+            for mode in ("plain", "pruned_no_seed", "pruned"):
+                if mode == "pruned_no_seed":
+                    monkeypatch.setenv("MI355SW_NO_DIAGONAL_SEED", "1")
+                else:
+                    monkeypatch.delenv("MI355SW_NO_DIAGONAL_SEED", raising=False)
+                mg = pkg.Stage1Manager(part, alignment_start=edge, alignment_end=edge, special_row_interval=1 << 20, block_pruning=mode != "plain")
+                al.alignPartition(part, mg)
+                st = al.getStatistics()
+                res[mode] = (mg, st)
+                assert st["profile_kernel"] == 2 and st["restarts"] == 0, (mode, st)
+            (a, sa), (b, sb), (c, sc) = res["plain"], res["pruned_no_seed"], res["pruned"]
+            assert tuple(a.getBestScore()) == tuple(b.getBestScore()) == tuple(c.getBestScore())
+            assert sa["seed_ms"] == 0 and sb["seed_ms"] == 0 and sc["seed_ms"] > 0
+            assert sa["pruned_cells"] == 0 and sc["pruned_cells"] > sb["pruned_cells"] > 0.2 * m * n
+            assert sc["pruned_cells"] > 0.6 * m * n                 # the seed finds the alignment: only what can tie it is left
+            best_row = a.getBestScore()[0]
+            assert sorted(a.special_rows) == sorted(c.special_rows) and len(a.special_rows) >= 4
+            for i in sorted(a.special_rows):
+                x, y = a.specialRow(i), c.specialRow(i)
+                assert np.all(y <= x), i
+                if edge == pkg.AT_ANYWHERE and i <= best_row:
+                    assert y[:, 0].max() == x[:, 0].max() and int(y[:, 0].argmax()) == int(x[:, 0].argmax()), i
+                if edge != pkg.AT_ANYWHERE:
+                    must = _reach(x[:, 0].astype(np.int64), i, np.arange(0, n + 1), m, n) >= a.getBestScore()[2]
+                    assert must.any() and np.array_equal(y[must, 0], x[must, 0]), i
+            print("edge %d: skipped %.3f without the seed, %.3f with it (seed %.0f ms); kernel %.0f -> %.0f ms" % (
+                edge, sb["pruned_cells"] / float(m) / n, sc["pruned_cells"] / float(m) / n, sc["seed_ms"], sb["kernel_ms"], sc["kernel_ms"]))
+    finally:
+        al.close()

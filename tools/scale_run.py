@@ -197,6 +197,48 @@ def case_c5band(out, m=249000000, n=28500000, k_rows=400, k_cols=48):
     assert out["check"]["ok"], out["check"]
 
 
+def case_c5band_pruned(out, m=249000000, n=28500000, n_total=228000000, k_rows=400):
+    """band 0 of C5 once more, as it runs in the pruning chain (round 4): block pruning ON against the lower bound of
+    H[249 M][228 M] -- the bound looks at all 228 M columns (prune_cols), the band's own cells supply it.  Alone, the band
+    only knows what its own stretch of the diagonal says about the last cell, so it skips the rows below ~203 M (in the
+    chain the bands to the right raise the bound and it skips more: profiles/r04_chain_nw_c5_quarter_8bands.json).  The
+    last column is kept as it would be streamed to band 1; pinned on: its first k_rows cells = the oracle's sweep of those
+    rows, -INF from the first skipped strip on, sha256 recorded."""
+    from masa_cudalign_amd.engine import NEEDLEMAN_WUNSCH, INIT_WITH_GAPS
+    s0, s1 = pkg.seqgen.related_pair(m, n, cfg=15)
+    part = pkg.Partition(0, 0, m, n)
+    al = pkg.MI355Aligner(device=0)
+    al.setSequences(s0, s1)
+    keep = {}
+
+    def borders(al):
+        hc, step, first_void, voids = hashlib.sha256(), 1 << 24, None, 0
+        for r0 in range(0, m, step):
+            col = al.streamReadColumn(r0, min(step, m - r0))
+            if r0 == 0:
+                keep["col_head"] = col[:k_rows].copy()
+            hc.update(np.ascontiguousarray(col).tobytes())
+            v = np.nonzero(col[:, 0] <= -900000000)[0]
+            voids += len(v)
+            if len(v) and first_void is None:
+                first_void = r0 + int(v[0])
+        return {"last_column_sha256": hc.hexdigest(), "first_skipped_row_of_the_last_column": first_void, "skipped_cells_of_the_last_column": voids}
+
+    r = run(al, part, before_end=borders, recurrence_type=NEEDLEMAN_WUNSCH, first_row_init_type=INIT_WITH_GAPS,
+            first_column_init_type=INIT_WITH_GAPS, want_last_column=True, track_best=False, prune_blocks=True, prune_rows=m, prune_cols=n_total)
+    al.close()
+    out.update(r)
+    oracle = g.load_oracle()
+    top = oracle.stage1(s0[:k_rows], s1, recurrence=NEEDLEMAN_WUNSCH, first_row_type=INIT_WITH_GAPS,
+                        first_col_type=INIT_WITH_GAPS, want_last_col=True, best_mode=oracle.BEST_LAST_CELL)
+    oc = np.asarray(top["last_col"])
+    oc = oc[-k_rows:] if len(oc) > k_rows else oc
+    out["check"] = {"last_column_head_rows": k_rows, "last_column_head_equal": bool((keep["col_head"] == oc).all()),
+                    "something_skipped": r["pruned_fraction"] > 0.1}
+    out["check"]["ok"] = all(v for v in out["check"].values() if isinstance(v, bool))
+    assert out["check"]["ok"], out["check"]
+
+
 def case_c4chain(out, m=59000000, w=8000000):
     """C4's height (59 M rows) as a chain of two column bands of w columns through the multi-GPU band driver
     (masa-cudalign_amd/bands.py, the code bench.py --gpus N runs), one band after the other on this one GPU with the
@@ -270,6 +312,10 @@ if __name__ == "__main__":
         case_nw_tall(out)
     elif case == "nwtallsmall":
         case_nw_tall(out, 40000000, 50000)
+    elif case == "c5band_pruned":
+        case_c5band_pruned(out)
+    elif case == "c5band_pruned_small":
+        case_c5band_pruned(out, 6000000, 400000, 5500000, 300)
     elif case == "c5band":
         case_c5band(out)
     elif case == "c5bandsmall":
