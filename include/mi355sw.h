@@ -261,6 +261,12 @@ typedef struct {
                                            and with the host through mi355sw_stream_best_hint / _running_best.  Block
                                            pruning then works against the best of the WHOLE matrix, which the
                                            reference gives up when it forks (M/libmasa/libmasa.cpp:1318-1321). */
+    int32_t have_initial_bound;         /* 1: `initial_bound` is valid */
+    int32_t initial_bound;              /* prune_blocks only: what the pruning bound starts from instead of "nothing known" -- the
+                                           score of a local alignment that exists (the best of a run that is being resumed,
+                                           of another node: Status::load / AlignerPool::getBestNodeScore in the reference), or
+                                           for a global alignment a lower bound of the last cell's score.  Without it, large
+                                           matrices get one from the diagonal seed pass (mi355sw_stats.seed_ms). */
 } mi355sw_stream_params;
 
 int mi355sw_stream_begin(mi355sw_handle* h, const mi355sw_partition* partition, const mi355sw_stream_params* p);

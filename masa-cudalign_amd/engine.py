@@ -95,7 +95,8 @@ class StreamParams(C.Structure):
                 ("special_row_interval", C.c_int32), ("track_best", C.c_int32), ("force_int32", C.c_int32),
                 ("prune_blocks", C.c_int32), ("prune_rows", C.c_int32), ("prune_cols", C.c_int32),
                 ("first_column_port", C.c_int32), ("last_column_port", C.c_int32),
-                ("first_column_resume_rows", C.c_int32), ("share_best", C.c_int32)]
+                ("first_column_resume_rows", C.c_int32), ("share_best", C.c_int32),
+                ("have_initial_bound", C.c_int32), ("initial_bound", C.c_int32)]
 
 
 class Stage4Stats(C.Structure):
@@ -430,7 +431,8 @@ class MI355Aligner:
                     first_column_start_offset=0, stream_first_column=False, first_column=None,
                     want_last_column=False, want_last_row=False, special_row_interval=0, track_best=True,
                     force_int32=False, prune_blocks=False, prune_rows=0, prune_cols=0,
-                    first_column_port=False, last_column_port=False, first_column_resume_rows=0, share_best=False):
+                    first_column_port=False, last_column_port=False, first_column_resume_rows=0, share_best=False,
+                    initial_bound=None):
         sp = StreamParams()
         sp.recurrence_type = recurrence_type
         sp.first_row_init_type, sp.first_row_start_offset = first_row_init_type, first_row_start_offset
@@ -448,6 +450,8 @@ class MI355Aligner:
         sp.first_column_port, sp.last_column_port = int(first_column_port), int(last_column_port)
         sp.first_column_resume_rows = int(first_column_resume_rows)
         sp.share_best = int(share_best)
+        if initial_bound is not None:
+            sp.have_initial_bound, sp.initial_bound = 1, int(initial_bound)
         self._check(self._lib.mi355sw_stream_begin(self._h, C.byref(partition), C.byref(sp)), "streamBegin")
         self._stream_part = partition
 

@@ -29,6 +29,10 @@
                            MASA-Core's stage 1 only asks for pruning when the alignment may end\n\
                            anywhere; with this option the engine also prunes whenever the score is\n\
                            read from the last cell, against a lower bound of that cell.\n\
+--no-diagonal-seed      Pruning runs of large matrices (8 Mi x 8 Mi and more) first sweep a narrow band\n\
+                           along the diagonal and start their pruning bound from the score found there;\n\
+                           this option leaves that pass out (use it with --max-alignments > 1: a strong\n\
+                           first bound prunes the weaker alignments away sooner).\n\
 "
 
 #define ARG_GPU        0x1001
@@ -37,6 +41,7 @@
 #define ARG_STRIP_ROWS 0x1004
 #define ARG_BLOCK_COLUMNS 0x1005
 #define ARG_PRUNE_GLOBAL 0x1006
+#define ARG_NO_DIAGONAL_SEED 0x1007
 
 static struct option long_options[] = {
     {"gpu",        required_argument, 0, ARG_GPU},
@@ -45,10 +50,11 @@ static struct option long_options[] = {
     {"strip-rows", required_argument, 0, ARG_STRIP_ROWS},
     {"block-columns", required_argument, 0, ARG_BLOCK_COLUMNS},
     {"prune-global", no_argument, 0, ARG_PRUNE_GLOBAL},
+    {"no-diagonal-seed", no_argument, 0, ARG_NO_DIAGONAL_SEED},
     {0, 0, 0, 0}
 };
 
-Mi355AlignerParameters::Mi355AlignerParameters() : gpu(MI355_DETECT_FASTEST_GPU), waves(0), stripRows(0), blockColumns(0), pruneGlobal(0) {}
+Mi355AlignerParameters::Mi355AlignerParameters() : gpu(MI355_DETECT_FASTEST_GPU), waves(0), stripRows(0), blockColumns(0), pruneGlobal(0), noDiagonalSeed(0) {}
 Mi355AlignerParameters::~Mi355AlignerParameters() {}
 
 void Mi355AlignerParameters::printUsage() const {
@@ -157,6 +163,9 @@ int Mi355AlignerParameters::processArgument(int argc, char** argv) {
         break;
     case ARG_PRUNE_GLOBAL:
         pruneGlobal = 1;
+        break;
+    case ARG_NO_DIAGONAL_SEED:
+        noDiagonalSeed = 1;
         break;
     default:
         return ret;

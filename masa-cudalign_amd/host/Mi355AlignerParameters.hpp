@@ -23,12 +23,13 @@ public:
     int getStripRows() const { return stripRows; }    /* --strip-rows: 256..2048, 0 = cost model */
     int getBlockColumns() const { return blockColumns; }   /* --block-columns: width of the blocks whose scores are dispatched, 0 = none */
     int getPruneGlobal() const { return pruneGlobal; }     /* --prune-global: block pruning of partitions whose goal is the last cell */
+    int getNoDiagonalSeed() const { return noDiagonalSeed; }   /* --no-diagonal-seed: MI355SW_F_NO_DIAGONAL_SEED */
     static void printGPUDevices(FILE* file);          /* --list-gpus (X/cuda_util.cpp:191-230) */
     static int fastestGPU();                          /* X/cuda_util.cpp:238-287: largest CUs x clock */
     static int deviceWeights(int* weights, int max);  /* X/cuda_util.cpp:191-257: per-GPU weights, asked from a child process */
 
 private:
-    int gpu, waves, stripRows, blockColumns, pruneGlobal;
+    int gpu, waves, stripRows, blockColumns, pruneGlobal, noDiagonalSeed;
 };
 
 #endif

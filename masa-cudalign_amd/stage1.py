@@ -146,9 +146,17 @@ def stage1(aligner, seq0, seq1, work, alignment_start=AT_ANYWHERE, alignment_end
     aligner.setSequences(v0, v1)
     t0 = time.time()
     stop_log = _start_progress_log(aligner, mgr, progress, progress_interval, t0)
+    # --max-alignments > 1: the weaker alignments are candidates too, and a pruning bound that starts from the score of the
+    # best one (the engine's diagonal seed pass) removes them sooner than a bound that grows with the sweep, as the
+    # reference's does -- the seed is left out then (include/mi355sw.h: MI355SW_F_NO_DIAGONAL_SEED)
+    seed_off = max_alignments != 1 and "MI355SW_NO_DIAGONAL_SEED" not in os.environ
+    if seed_off:
+        os.environ["MI355SW_NO_DIAGONAL_SEED"] = "1"
     try:
         aligner.alignPartition(rel, mgr)
     finally:
+        if seed_off:
+            del os.environ["MI355SW_NO_DIAGONAL_SEED"]
         stop_log()
         if part_sra is not None:
             part_sra.close()

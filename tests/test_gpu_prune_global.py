@@ -257,12 +257,12 @@ def test_local_pruning_far_above_the_16_bit_window(pkg):
 
 
 def test_diagonal_seed_gives_the_same_answers_and_prunes_more(pkg, monkeypatch):
-    """5 M x 4.5 M related pair: a pruning run of a large matrix gets its first bound from a staircase of tiles along the
+    """9 M x 8.5 M related pair: a pruning run of a large matrix gets its first bound from a staircase of tiles along the
     diagonal (runtime.cpp::diagonal_seed; the reference seeds its bound with the best of a resumed run or of the other
     nodes, sw_stage1.cpp:210-217, AlignerPool).  The seed is the score of a real alignment, so nothing may change but the
     amount of work: same best cell (local) / same H[m][n] (global) as without the seed and as without pruning, special
     rows lower bounds of the unpruned ones with the row maxima intact above the best cell, more cells skipped."""
-    m, n = 5000000, 4500000
+    m, n = 9000000, 8500000                      # (the seed only runs from 8 Mi x 8 Mi: below that it costs more than it saves)
     s0, s1 = pkg.seqgen.related_pair(m, n, cfg=37)
     part = pkg.Partition(0, 0, m, n)
     al = pkg.MI355Aligner(device=0)

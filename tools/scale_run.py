@@ -109,6 +109,43 @@ def case_c3(out, m=48000000, n=46000000):
     assert out["same_best"] and out["rows_lower_bound"] and out["row_max_equal_above_best"], out
 
 
+def case_c3_pruned_only(out, ref_json, m=48000000, n=46000000):
+    """C3's stage 1 with pruning only (the unpruned sweep costs six minutes): best cell and the maximum of every special
+    row above it against the UNPRUNED run recorded in `ref_json` (profiles/r04_scale_c3_48Mx46M.json)"""
+    ref = json.load(open(ref_json))["unpruned"]
+    s0, s1 = pkg.seqgen.related_pair(m, n, cfg=3)
+    al = pkg.MI355Aligner(device=0, max_special_bytes=64 << 30)
+    al.setSequences(s0, s1)
+    part = pkg.Partition(0, 0, m, n)
+
+    def read_rows(al):
+        rows, k = [], 0
+        while True:
+            try:
+                dp, cells = al.streamReadSpecialRow(k)
+            except pkg.engine.AlignerError:
+                break
+            h = np.ascontiguousarray(cells[:, 0])
+            rows.append({"dp_row": int(dp), "max_h": int(h.max()), "argmax": int(h.argmax())})
+            k += 1
+        return rows
+    t0 = time.time()
+    r = run(al, part, before_end=read_rows, prune_blocks=True, special_row_interval=m // 20)
+    out["wall_with_seed_s"] = time.time() - t0
+    st = al.getStatistics()
+    out["seed_ms"] = st["seed_ms"]
+    al.close()
+    out["pruned"] = r
+    out["gcups_mn_incl_seed"] = float(m) * n / (st["kernel_ms"] + st["seed_ms"]) / 1e6
+    out["same_best"] = r["best"] == ref["best"]
+    bi = ref["best"][0]
+    want = {x["dp_row"]: x for x in ref["rows"]}
+    out["row_max_equal_above_best"] = all(x["max_h"] == want[x["dp_row"]]["max_h"] and x["argmax"] == want[x["dp_row"]]["argmax"]
+                                          for x in r["rows"] if x["dp_row"] <= bi)
+    out["rows_lower_bound_of_recorded_maxima"] = all(x["max_h"] <= want[x["dp_row"]]["max_h"] for x in r["rows"])
+    assert out["same_best"] and out["row_max_equal_above_best"] and out["rows_lower_bound_of_recorded_maxima"], out
+
+
 def case_nw_tall(out, m=249000000, n=500000):
     """C5's height (249 M rows, beyond the reference's 134 M texture limit) as a global NW with gap-initialised
     borders: the packed kernel (window follows the scores down to -5e8) and the int32 kernel must agree on
@@ -298,6 +335,8 @@ if __name__ == "__main__":
     out = {"case": case}
     if case == "c3":
         case_c3(out)
+    elif case == "c3pruned":
+        case_c3_pruned_only(out, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r04_scale_c3_48Mx46M.json"))
     elif case == "c3small":
         case_c3(out, 6000000, 5000000)
     elif case == "tall":
