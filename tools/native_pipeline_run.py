@@ -32,6 +32,20 @@ def main():
     q1 = fasta.Sequence(">s1", s1, fasta.SequenceModifiers())
     work = os.environ.get("MI355SW_WORK") or tempfile.mkdtemp(prefix="mi355_native_")
     al = pkg.MI355Aligner(device=0)
+    prof_fn = os.environ.get("MI355SW_PROFILE_STAGE2")        # cProfile of stage 2 alone, as text
+    if prof_fn:
+        import cProfile, io, pstats
+        real_stage2 = pipeline.stage2
+
+        def profiled_stage2(*a, **kw):
+            pr = cProfile.Profile()
+            try:
+                return pr.runcall(real_stage2, *a, **kw)
+            finally:
+                buf = io.StringIO()
+                pstats.Stats(pr, stream=buf).sort_stats("cumulative").print_stats(45)
+                open(prof_fn, "w").write(buf.getvalue())
+        pipeline.stage2 = profiled_stage2
     t0 = time.time()
     try:
         out = pipeline.align(al, q0, q1, work, sra_limit=limit)
