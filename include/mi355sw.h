@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define MI355SW_ABI_VERSION 5
+#define MI355SW_ABI_VERSION 6
 
 /* M/libmasa/libmasaTypes.hpp:35-41  cell_t {int h; union{int f; int e;};} 8-byte aligned */
 typedef struct { int32_t h; int32_t f; } mi355sw_cell;
@@ -270,6 +270,16 @@ typedef struct {
 } mi355sw_stream_params;
 
 int mi355sw_stream_begin(mi355sw_handle* h, const mi355sw_partition* partition, const mi355sw_stream_params* p);
+/* The diagonal seed pass on its own, for callers that divide one matrix among several streams (a chain of column bands, one GPU
+ * each: a band cannot make the seed of the whole matrix, and mi355sw_stream_begin leaves it out for streams with column ports
+ * or a streamed first column).  `partition` = the WHOLE matrix, borders as the run will have them: zeroes for SMITH_WATERMAN,
+ * gap penalties from the origin for NEEDLEMAN_WUNSCH (a global alignment).  *have_bound = 1 and *bound = the value for
+ * mi355sw_stream_params.initial_bound of every band (the score of a local alignment that exists / a lower bound of the last
+ * cell's score); *have_bound = 0 when there is none: an unrelated pair (local), a matrix below 64 Ki x 16 Ki, sequences the
+ * packed kernel cannot take.  No stream may be active on the handle; mi355sw_stats.seed_ms of the next stream reports its time.
+ * Reference: the bound a node starts from -- Status::load -> BestScoreList (sw_stage1.cpp:210-217) and the other nodes' best
+ * score, AlignerPool::getBestNodeScore (M/common/AlignerPool.cpp:182-184). */
+int mi355sw_seed_bound(mi355sw_handle* h, const mi355sw_partition* partition, int32_t recurrence_type, int32_t* have_bound, int32_t* bound);
 /* cells[0..len) = (H,E) of rows [row, row+len) of column j0-1 ; rows must arrive in order */
 int mi355sw_stream_feed_column(mi355sw_handle* h, int32_t row, const mi355sw_cell* cells, int32_t len);
 /* number of DP rows whose strips are complete (monotonic); *finished = 1 when the kernel ended */

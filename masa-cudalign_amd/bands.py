@@ -64,6 +64,25 @@ def canonical_best(cands):
     return best
 
 
+SEED_MIN_EXTENT = 8 << 20            # rows and columns from which the diagonal seed pays (as in mi355sw_stream_begin)
+NO_BOUND = -(1 << 40)                # "no bound" in the start token that travels along the chain
+
+
+def chain_seed_bound(engine, m, n, recurrence, first_row_init_type, first_col_init_type):
+    """What the pruning bound of every band of a chain starts from: the diagonal seed pass over the WHOLE m x n matrix
+    (mi355sw_seed_bound), run once on `engine`'s GPU before the first band starts.  A single partition gets it from
+    mi355sw_stream_begin by itself; a band cannot (it sees its own columns, and its borders are ports), and without it
+    each band prunes only against what the chain has found so far -- at 62 M x 57 M, 41 % of the cells instead of 75 %.
+    None where the pass does not apply: small matrices, borders other than the recurrence's own (zeroes for a local
+    alignment, gap penalties from the origin for a global one), an engine without the entry point, MI355SW_NO_DIAGONAL_SEED."""
+    if m < SEED_MIN_EXTENT or n < SEED_MIN_EXTENT or not hasattr(engine, "seedBound") or os.environ.get("MI355SW_NO_DIAGONAL_SEED"):
+        return None
+    own = INIT_WITH_ZEROES if recurrence == SMITH_WATERMAN else 1          # 1 = INIT_WITH_GAPS
+    if first_row_init_type != own or first_col_init_type != own:
+        return None
+    return engine.seedBound(Partition(0, 0, m, n), recurrence)
+
+
 class BandRunner:
     """Runs one band of the chain on this rank.  `dist` is torch.distributed (already initialised) or an object
     with send/recv/all_gather, or None for a single band.  All ranks must call run() with the same m.
@@ -78,9 +97,11 @@ class BandRunner:
     `device` is only the device of the tensors used for collectives (reduce_best)."""
 
     def __init__(self, engine, dist=None, rank=0, world=1, device=None, segment_rows=1 << 16, prune_blocks=False,
-                 transport="host"):
+                 transport="host", seed_bound=True):
         self.engine, self.dist, self.rank, self.world = engine, dist, rank, world
         self.prune_blocks = prune_blocks
+        self.seed_bound = seed_bound   # pruning chains: band 0 runs the diagonal seed of the whole matrix first (chain_seed_bound)
+        self.initial_bound = None      # ... and this is what the last run's bound started from
         self.device = device
         self.segment_rows = segment_rows
         self.transport = transport if world > 1 else "none"
@@ -271,24 +292,34 @@ class BandRunner:
         # The token always travels, whatever happens to this band's own start: 1 = started, 0 = failed (no memory for the
         # special rows, a port that is not there) -- a band that never hears from its left neighbour would sit in recv
         # with no kernel running and nothing for the stall watchdog to see, and so would every band to its right.
-        if not first and dist is not None:
+        # With the token travels what the pruning bound starts from: band 0 runs the diagonal seed pass of the WHOLE matrix
+        # before it starts (the bands to its right could not start earlier anyway) and every band begins with that value.
+        def token(ok, bound):
             import torch
-            go = torch.zeros(1, dtype=torch.uint8)
+            return torch.tensor([1 if ok else 0, NO_BOUND if bound is None else int(bound)], dtype=torch.int64)
+
+        bound = None
+        if not first and dist is not None:
+            go = token(False, None)
             dist.recv(go, src=self.rank - 1)
             if int(go[0]) != 1:
                 if not last:
-                    dist.send(torch.zeros(1, dtype=torch.uint8), dst=self.rank + 1)
+                    dist.send(token(False, None), dst=self.rank + 1)
                 raise RuntimeError("band %d/%d: a band to the left failed to start its kernel" % (self.rank, self.world))
+            bound = None if int(go[1]) == NO_BOUND else int(go[1])
         try:
+            if first and prune and self.seed_bound and self.world > 1 and n_total is not None:
+                bound = chain_seed_bound(eng, m, n_total, recurrence, first_row_init_type, first_col_init_type)
+            if prune and bound is not None:
+                kw.update(initial_bound=bound)
+            self.initial_bound = bound
             eng.streamBegin(part, **kw)
         except BaseException:
             if not last and dist is not None:
-                import torch
-                dist.send(torch.zeros(1, dtype=torch.uint8), dst=self.rank + 1)
+                dist.send(token(False, None), dst=self.rank + 1)
             raise
         if not last and dist is not None:
-            import torch
-            dist.send(torch.ones(1, dtype=torch.uint8), dst=self.rank + 1)
+            dist.send(token(True, bound), dst=self.rank + 1)
         self.restarts = 0
 
         lock = threading.Lock()          # the engine handle is driven by one thread at a time
@@ -543,9 +574,11 @@ class InProcessChain:
     forked processes chained by sockets (M/libmasa/libmasa.cpp:540-642).
     Score passes only (best cell, or H[m][n] of a global alignment): special rows per band are BandRunner's job."""
 
-    def __init__(self, aligners, prune_blocks=False):
+    def __init__(self, aligners, prune_blocks=False, seed_bound=True):
         self.aligners = list(aligners)
         self.prune_blocks = prune_blocks
+        self.seed_bound = seed_bound       # pruning: the diagonal seed of the whole matrix first (chain_seed_bound)
+        self.initial_bound = None
         self.restarts = 0
         self._rows = 0
 
@@ -570,6 +603,9 @@ class InProcessChain:
         n = limits[-1]
         sw = recurrence == SMITH_WATERMAN
         self.attach(m)
+        self.initial_bound = None
+        if self.prune_blocks and self.seed_bound and N > 1:
+            self.initial_bound = chain_seed_bound(als[0], m, n, recurrence, first_row_init_type, first_col_init_type)
         for attempt in (0, 1):
             begun = []
             try:
@@ -579,6 +615,8 @@ class InProcessChain:
                               force_int32=bool(force_int32 or attempt))
                     if self.prune_blocks:
                         kw.update(prune_blocks=True, prune_rows=m, prune_cols=n - limits[k], share_best=N > 1)
+                        if self.initial_bound is not None:
+                            kw.update(initial_bound=self.initial_bound)
                     if k == 0:
                         kw.update(first_column_init_type=first_col_init_type)
                     else:

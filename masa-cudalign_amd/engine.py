@@ -148,7 +148,7 @@ ABI_SYMBOLS = [
     "mi355sw_set_sequences", "mi355sw_unset_sequences", "mi355sw_align_partition", "mi355sw_align_partitions",
     "mi355sw_process_block", "mi355sw_match_last_column", "mi355sw_progress",
     "mi355sw_processed_cells", "mi355sw_get_stats",
-    "mi355sw_stream_begin", "mi355sw_stream_feed_column", "mi355sw_stream_poll",
+    "mi355sw_stream_begin", "mi355sw_seed_bound", "mi355sw_stream_feed_column", "mi355sw_stream_poll",
     "mi355sw_stream_read_column", "mi355sw_stream_read_special_row", "mi355sw_stream_read_last_row",
     "mi355sw_stream_abort", "mi355sw_stream_end", "mi355sw_stream_strip_scores",
     "mi355sw_stream_best_hint", "mi355sw_stream_running_best",
@@ -215,6 +215,7 @@ def load_library():
     lib.mi355sw_processed_cells.restype = C.c_longlong
     lib.mi355sw_get_stats.argtypes = [H, C.POINTER(Stats)]
     lib.mi355sw_stream_begin.argtypes = [H, C.POINTER(Partition), C.POINTER(StreamParams)]
+    lib.mi355sw_seed_bound.argtypes = [H, C.POINTER(Partition), C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     lib.mi355sw_stream_feed_column.argtypes = [H, C.c_int32, C.c_void_p, C.c_int32]
     lib.mi355sw_stream_poll.argtypes = [H, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     lib.mi355sw_stream_read_column.argtypes = [H, C.c_int32, C.c_void_p, C.c_int32]
@@ -426,6 +427,14 @@ class MI355Aligner:
         return out
 
     # -- streaming form (column-band driver) ---------------------------------------------------
+    def seedBound(self, partition, recurrence_type=SMITH_WATERMAN):
+        """mi355sw_seed_bound: the diagonal seed pass over `partition` -- the WHOLE matrix a chain of bands divides among itself
+        -- on this engine's GPU; returns the value for streamBegin(initial_bound=...) of every band, or None when there is
+        none (an unrelated pair, a small matrix)."""
+        have, bound = C.c_int32(0), C.c_int32(0)
+        self._check(self._lib.mi355sw_seed_bound(self._h, C.byref(partition), int(recurrence_type), C.byref(have), C.byref(bound)), "seedBound")
+        return int(bound.value) if have.value else None
+
     def streamBegin(self, partition, recurrence_type=SMITH_WATERMAN, first_row_init_type=INIT_WITH_ZEROES,
                     first_row_start_offset=0, first_row=None, first_column_init_type=INIT_WITH_ZEROES,
                     first_column_start_offset=0, stream_first_column=False, first_column=None,

@@ -22,6 +22,7 @@ from .stage1 import stage1
 from .stage2 import stage2
 from .stage3 import stage3
 from . import stage56, alignment_file
+from . import sra as sra_mod
 
 
 class WorkDirectoryMismatch(RuntimeError):
@@ -50,6 +51,7 @@ def check_work_directory(work, seq0, seq1):
             f.write("seq0=%s\nseq1=%s\n" % (seq0.description, seq1.description))
 
 
+@sra_mod.with_async_files
 def align(aligner, seq0, seq1, work, alignment_start=AT_ANYWHERE, alignment_end=AT_ANYWHERE, sra_limit=0,
           block_pruning=True, max_partition_size=16, progress=None, max_alignments=1, ram_limit=0):
     """seq0, seq1: fasta.Sequence.  Returns {"best", "alignment": stage56.Alignment or None, "text": bytes of

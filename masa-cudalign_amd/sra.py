@@ -14,7 +14,12 @@ A row is written as <rowid>.tmp and renamed when its last cell has arrived (Spec
 killed run leaves only complete rows (plus .tmp files that the next run deletes), and the last complete row is the
 checkpoint stage 1 continues from (SpecialRowsPartition::continueFromLastRow, :454-462; sw_stage1.cpp:210-217).
 """
+import atexit
+import collections
+import contextlib
+import functools
 import os
+import threading
 
 import numpy as np
 
@@ -23,6 +28,128 @@ from .engine import INF, INIT_WITH_ZEROES, INIT_WITH_GAPS, INIT_WITH_CUSTOM_DATA
 INIT_NAMES = {INIT_WITH_ZEROES: "INIT_WITH_ZEROES", INIT_WITH_GAPS: "INIT_WITH_GAPS",
               INIT_WITH_CUSTOM_DATA: "INIT_WITH_CUSTOM_DATA", INIT_WITH_GAPS_OPENED: "INIT_WITH_GAPS_OPENED"}
 CELL_BYTES = 8
+
+
+class _FileQueue:
+    """The file operations of an area -- create, write, close + rename, remove, truncate, rename of a directory, status
+    file -- carried out by ONE thread in the order they were asked for, while a stage runs (`async_files()`).  A special
+    row is tens to hundreds of megabytes handed over inside an engine callback; written inline, the page-cache copy is time
+    the aligner's thread does not spend on the running kernel (C3, stage 2: 29 GB, 3.9 of its 15 s).  Order is what the
+    on-disk protocol needs -- a row is renamed into place before the status file that names it -- and one thread keeps
+    it.  Readers wait: for one partition's operations (`wait(owner)`) or for everything (`drain()`).  Outside
+    `async_files()` every operation runs at once, in the caller's thread."""
+
+    MAX_BYTES = 1 << 30             # cells waiting to be written (the submitter waits above that)
+
+    def __init__(self):
+        self.cv = threading.Condition()
+        self.q = collections.deque()
+        self.depth = 0              # nesting of async_files()
+        self.bytes = 0
+        self.running = None         # owner of the operation being carried out
+        self.pending = {}           # id(owner) -> operations not finished
+        self.error = None
+        self.thread = None
+        self.pid = None
+
+    def _enabled(self):
+        return self.depth > 0 and not os.environ.get("MI355SW_SRA_SYNC")
+
+    def submit(self, owner, fn, *args, nbytes=0):
+        if not self._enabled():
+            self.drain()
+            fn(*args)
+            return
+        with self.cv:
+            if self.error is not None:
+                self._raise()
+            if self.thread is None or self.pid != os.getpid() or not self.thread.is_alive():
+                self.pid = os.getpid()
+                self.thread = threading.Thread(target=self._run, name="mi355sw-sra-files", daemon=True)
+                self.thread.start()
+            while self.bytes > self.MAX_BYTES and self.error is None:
+                self.cv.wait()
+            self.q.append((owner, fn, args, nbytes))
+            self.bytes += nbytes
+            self.pending[id(owner)] = self.pending.get(id(owner), 0) + 1
+            self.cv.notify_all()
+
+    def _run(self):
+        while True:
+            with self.cv:
+                while not self.q:
+                    self.cv.wait()
+                owner, fn, args, nbytes = self.q.popleft()
+            try:
+                if self.error is None:          # after a failure nothing more touches the files
+                    fn(*args)
+            except BaseException as e:          # noqa: BLE001 -- handed to the thread that asked
+                with self.cv:
+                    self.error = e
+            with self.cv:
+                self.bytes -= nbytes
+                k = self.pending.get(id(owner), 1) - 1
+                if k > 0:
+                    self.pending[id(owner)] = k
+                else:
+                    self.pending.pop(id(owner), None)
+                self.cv.notify_all()
+
+    def _raise(self):
+        e, self.error = self.error, None
+        self.q.clear()
+        self.pending.clear()
+        self.bytes = 0
+        raise RuntimeError("special rows area: a queued file operation failed: %r" % (e,)) from e
+
+    def wait(self, owner):
+        """until every operation asked for on behalf of `owner` has been carried out"""
+        if self.pid != os.getpid():
+            return
+        with self.cv:
+            while self.pending.get(id(owner), 0) > 0 and self.error is None and self.thread is not None and self.thread.is_alive():
+                self.cv.wait(1.0)
+            if self.error is not None:
+                self._raise()
+
+    def drain(self):
+        if self.pid != os.getpid():
+            return
+        with self.cv:
+            while self.pending and self.error is None and self.thread is not None and self.thread.is_alive():
+                self.cv.wait(1.0)
+            if self.error is not None:
+                self._raise()
+
+
+_files = _FileQueue()
+atexit.register(lambda: _files.drain())
+
+
+def drain():
+    """every queued file operation has been carried out when this returns"""
+    _files.drain()
+
+
+@contextlib.contextmanager
+def async_files():
+    """while the block runs, the areas' file operations are queued (see _FileQueue); all carried out when it ends"""
+    _files.depth += 1
+    try:
+        yield
+    finally:
+        _files.depth -= 1
+        if _files.depth == 0:
+            _files.drain()
+
+
+def with_async_files(fn):
+    """decorator: the function's body runs inside async_files()"""
+    @functools.wraps(fn)
+    def wrapper(*args, **kwargs):
+        with async_files():
+            return fn(*args, **kwargs)
+    return wrapper
 
 
 def special_rows_path(work, stage=1, ident=0, deep=-1):
@@ -46,21 +173,40 @@ def write_crosspoint(path, best, typ=0):
 
 
 class _OpenRow:
-    def __init__(self, path, rowid, width_cells):
+    def __init__(self, path, rowid, width_cells, owner=None):
         self.final = os.path.join(path, "%08X" % rowid)
         self.tmp = self.final + ".tmp"
-        self.f = open(self.tmp, "wb")
-        self.f.truncate(width_cells * CELL_BYTES)      # SpecialRowFile::initialize: the file has its final size at once
+        self.owner = owner
+        self.f = None
         self.offset = 0
+        _files.submit(owner, self._create, width_cells)
+
+    def _create(self, width_cells):
+        self.f = open(self.tmp, "wb", buffering=0)
+        self.f.truncate(width_cells * CELL_BYTES)      # SpecialRowFile::initialize: the file has its final size at once
+
+    def _write(self, data):
+        view = memoryview(data)
+        while len(view):                               # a raw file may take less than it was given
+            view = view[self.f.write(view):]
 
     def write(self, cells):
         a = np.ascontiguousarray(cells, dtype=np.int32)
-        self.f.write(a.tobytes())
+        if _files._enabled():
+            data = a.tobytes()                         # the caller's buffer is only lent for the call
+            _files.submit(self.owner, self._write, data, nbytes=len(data))
+        else:
+            _files.drain()
+            self._write(a.reshape(-1).view(np.uint8))
         self.offset += a.shape[0]
 
-    def close(self):
+    def _close(self, rename):
         self.f.close()
-        os.replace(self.tmp, self.final)
+        if rename:
+            os.replace(self.tmp, self.final)
+
+    def close(self, rename=True):
+        _files.submit(self.owner, self._close, rename)
 
 
 class _OpenRamRow:
@@ -106,6 +252,7 @@ class SpecialRowReader:
         ram = self.partition._ram.get(self.id)
         if ram is not None:
             return ram[offset:offset + length]
+        _files.wait(self.partition)
         fn = os.path.join(self.partition.path, "%08X" % self.id)
         a = np.fromfile(fn, dtype=np.int32, count=2 * length, offset=CELL_BYTES * offset).reshape(-1, 2)
         if a.shape[0] != length:
@@ -120,6 +267,18 @@ class SpecialRowReader:
         if buf is not None:
             buf[:length] = self._cells(self.offset, length)[::-1]
         return length
+
+
+def _shorten(fn, size):
+    if size < os.path.getsize(fn):
+        os.truncate(fn, size)
+
+
+def _move_directory(old, new):
+    if os.path.isdir(new):             # left by an earlier run of the same stage in this work directory
+        import shutil
+        shutil.rmtree(new)
+    os.rename(old, new)
 
 
 class SpecialRowsPartition:
@@ -148,16 +307,23 @@ class SpecialRowsPartition:
             return
         self.path = os.path.join(area_path, "%08X.%08X.%08X.%08X" % (i0, j0, i1, j1))
         if read_only:
+            _files.drain()
             if not os.path.isdir(self.path):
                 raise RuntimeError("special rows partition %s does not exist" % self.path)
         else:
-            os.makedirs(self.path, exist_ok=True)
+            os.makedirs(os.path.dirname(self.path), exist_ok=True)
+            try:
+                os.mkdir(self.path)
+                return                 # a directory made just now holds nothing to read (and nothing queued can touch it)
+            except FileExistsError:
+                pass
         self.read_directory()
 
     # -- directory ---------------------------------------------------------------------------------------------
     def read_directory(self):
         """SpecialRowsPartition::readDirectory (:343-381): complete rows are 8 hex digits; leftovers of a killed run
         (<id>.tmp) are removed (SpecialRowFile.cpp:40-47)"""
+        _files.drain()
         rows = []
         for fn in os.listdir(self.path):
             if len(fn) == 12 and fn.endswith(".tmp"):
@@ -263,8 +429,7 @@ class SpecialRowsPartition:
                 if isinstance(row, _OpenRamRow):
                     self._ram[rid] = row.cells
                 else:
-                    row.f.close()
-                    os.replace(row.tmp, row.final)      # SpecialRowFile::close renames whatever was written
+                    row.close()                         # SpecialRowFile::close renames whatever was written
                 if rid not in self.rows:
                     self.rows.append(rid)
             self._open = {}
@@ -278,10 +443,9 @@ class SpecialRowsPartition:
                     continue
                 fn = os.path.join(self.path, "%08X" % rid)
                 if rid + self.i0 >= max_i:
-                    os.remove(fn)
+                    _files.submit(self, os.remove, fn)
                 else:
-                    if cells * CELL_BYTES < os.path.getsize(fn):
-                        os.truncate(fn, cells * CELL_BYTES)
+                    _files.submit(self, _shorten, fn, cells * CELL_BYTES)
                     keep.append(rid)
             self.rows = keep
         self.i1, self.j1 = max_i, max_j
@@ -289,10 +453,7 @@ class SpecialRowsPartition:
 
     def change_path(self, new_path):
         if self.persistent and new_path != self.path:
-            if os.path.isdir(new_path):            # left by an earlier run of the same stage in this work directory
-                import shutil
-                shutil.rmtree(new_path)
-            os.rename(self.path, new_path)
+            _files.submit(self, _move_directory, self.path, new_path)
             self.path = new_path
 
     @property
@@ -309,6 +470,7 @@ class SpecialRowsPartition:
     def read_row(self, i):
         if (i - self.i0) in self._ram:
             return self._ram[i - self.i0]
+        _files.wait(self)
         return np.fromfile(self.row_filename(i), dtype=np.int32).reshape(-1, 2)
 
     def last_disk_row_id(self):
@@ -333,7 +495,7 @@ class SpecialRowsPartition:
         rid = i - self.i0
         row = self._open.get(rid)
         if row is None:
-            row = self._open[rid] = (_OpenRow(self.path, rid, self.width_cells) if self._next_row_on_disk()
+            row = self._open[rid] = (_OpenRow(self.path, rid, self.width_cells, self) if self._next_row_on_disk()
                                      else _OpenRamRow(rid, self.width_cells))
         row.write(cells)
         if row.offset >= self.width_cells:
@@ -351,7 +513,7 @@ class SpecialRowsPartition:
     def close(self):
         for row in self._open.values():
             if not isinstance(row, _OpenRamRow):
-                row.f.close()          # incomplete rows stay .tmp: the next read_directory() removes them
+                row.close(rename=False)          # incomplete rows stay .tmp: the next read_directory() removes them
         self._open = {}
 
     # -- resume (continueFromLastRow, :454-462) ----------------------------------------------------------------
@@ -399,6 +561,7 @@ class SpecialRowsArea:
 
     def open_partition_at(self, i, j):
         """openPartition(i, j) (:118-146): the partition whose cells (border excluded) hold DP cell (i, j)"""
+        _files.drain()
         for name in os.listdir(self.directory):
             tok = name.split(".")
             if len(tok) == 4 and all(len(t) == 8 for t in tok):
@@ -453,6 +616,7 @@ class Status:
         self.value_best = None
         self.value_key = None          # what the value belongs to: (i0, j0, i1, j1, alignment start, alignment end)
         self.loaded = False
+        _files.drain()
         if os.path.exists(self.side):
             tok = open(self.side).read().split()
             if len(tok) >= 3:
@@ -476,24 +640,31 @@ class Status:
             self.value_best = tuple(int(x) for x in cand)
 
     def save(self, best=None):
+        """queued behind the rows written so far (see _FileQueue): on disk, a status never names a row that is not"""
+        side = None
         if self.value_best is not None:
-            with open(self.side + ".tmp", "w") as f:
-                f.write("%d %d %d" % self.value_best)
-                if self.value_key is not None:
-                    f.write(" %d %d %d %d %d %d" % tuple(self.value_key))
-                f.write("\n")
-            os.replace(self.side + ".tmp", self.side)
+            side = "%d %d %d" % self.value_best
+            if self.value_key is not None:
+                side += " %d %d %d %d %d %d" % tuple(self.value_key)
+            side += "\n"
         if best is not None:
             self.best = tuple(int(x) for x in best)
         b = self.best if self.best is not None else (-1, -1, -INF)
-        with open(self.tmp, "w") as f:
-            f.write("%d\n%d\n%d %d %d\n" % (self.stage, self.last_special_row, b[0], b[1], b[2]))
-        os.replace(self.tmp, self.file)
+        _files.submit(self, self._save, side, "%d\n%d\n%d %d %d\n" % (self.stage, self.last_special_row, b[0], b[1], b[2]))
 
+    def _save(self, side, text):
+        if side is not None:
+            with open(self.side + ".tmp", "w") as f:
+                f.write(side)
+            os.replace(self.side + ".tmp", self.side)
+        with open(self.tmp, "w") as f:
+            f.write(text)
+        os.replace(self.tmp, self.file)
 
     def drop_value_best(self):
         """stage 1 is complete: the value-only record of a two-phase run has served its purpose"""
         self.value_best = self.value_key = None
+        _files.drain()
         for fn in (self.side, self.side + ".tmp"):
             if os.path.exists(fn):
                 os.remove(fn)

@@ -67,6 +67,7 @@ def _crosspoints_on_disk(work):
     return out
 
 
+@sra_mod.with_async_files
 def stage1(aligner, seq0, seq1, work, alignment_start=AT_ANYWHERE, alignment_end=AT_ANYWHERE, sra_limit=0,
            block_pruning=True, manager_class=Stage1Manager, bounds=None, progress=None, progress_interval=2.0,
            max_alignments=1, ram_limit=0, areas=None):

@@ -83,6 +83,7 @@ def find_next_crosspoint(mgr, area, c0, c1, alignment_start, must_find=True, goa
     return conclude_next_crosspoint(mgr, area, part, c0, c1, must_find)
 
 
+@sra_mod.with_async_files
 def stage2(aligner, seq0, seq1, work, alignment_start=AT_ANYWHERE, sra_limit=0, ident=0, bounds=None, ram_limit=0,
            areas=None):
     """Runs stage 2 for alignment `ident` of work directory `work` (stage 1 must have left crosspoint_01.NN and,

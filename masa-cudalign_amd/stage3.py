@@ -142,6 +142,7 @@ def _reduce_partitions(mgr, prev, out, seq_v, seq_h, area_prev, area, reverse):
     return sweeps
 
 
+@sra_mod.with_async_files
 def stage3(aligner, seq0, seq1, work, sra_limit=0, ident=0, ram_limit=0, areas=None):
     """Runs stage 3 for alignment `ident`.  Returns {"crosspoints": the final list [(type, i, j, score)] in original
     coordinates (also written to crosspoint_03.NN), "rounds": [(crosspoints in, crosspoints out, sweeps)], "seconds"}."""

@@ -550,3 +550,83 @@ def test_chain_in_one_process_on_one_device(pkg, recurrence):
     finally:
         for a in als + [ref]:
             a.close()
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("recurrence", ["sw", "nw"])
+def test_chain_takes_its_first_bound_from_the_diagonal_seed(pkg, recurrence):
+    """A chain that prunes starts from the diagonal seed of the WHOLE matrix (bands.chain_seed_bound -> mi355sw_seed_bound):
+    three bands of a 9 M x 8.5 M related pair side by side on cuda:0, with and without it -- the same answer, the seed's value
+    is the answer itself on this pair (local) or a lower bound of it (global), and far more of the matrix goes."""
+    from masa_cudalign_amd.bands import InProcessChain, band_limits
+    world, m, n = 3, 9000000, 8500000
+    s0, s1 = pkg.seqgen.related_pair(m, n, cfg=5)
+    als = [pkg.MI355Aligner(device=0, waves=336) for _ in range(world)]
+    try:
+        for a in als:
+            a.setSequences(s0, s1)
+        kw = dict(recurrence=pkg.NEEDLEMAN_WUNSCH, first_row_init_type=pkg.INIT_WITH_GAPS, first_col_init_type=pkg.INIT_WITH_GAPS) if recurrence == "nw" else {}
+        out = {}
+        for seed in (False, True):
+            chain = InProcessChain(als, prune_blocks=True, seed_bound=seed)
+            best, stats = chain.run(m, band_limits(n, [1] * world), **kw)
+            out[seed] = (tuple(best), sum(s["pruned_cells"] for s in stats) / float(m) / n, chain.initial_bound, chain.restarts)
+        assert out[False][0] == out[True][0], out
+        assert out[False][2] is None and out[True][2] is not None and out[False][3] == out[True][3] == 0
+        if recurrence == "sw":
+            assert out[True][2] == out[True][0][2], out                 # the staircase holds the whole alignment of this pair
+        else:
+            assert out[True][2] <= out[True][0][2] and out[True][2] > out[True][0][2] - 100000, out
+        assert out[True][1] > out[False][1] + 0.15 and out[True][1] > 0.6, out
+        # an unrelated pair has nothing to follow: no bound, and the chain runs as it did
+        u0, u1 = pkg.seqgen.unrelated_pair(m, 8400000, cfg=5)
+        if recurrence == "sw":
+            als[0].setSequences(u0, u1)
+            assert als[0].seedBound(pkg.Partition(0, 0, m, 8400000)) is None
+    finally:
+        for a in als:
+            a.close()
+
+
+def _worker_seeded(rank, world, port, m, n, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    import __graft_entry__ as graft
+    pkg = graft.load_package()
+    from masa_cudalign_amd.bands import BandRunner, band_limits
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        s0, s1 = pkg.seqgen.related_pair(m, n, cfg=5)
+        lim = band_limits(n, [1] * world)
+        al = pkg.MI355Aligner(device=0, waves=1024 // world)
+        al.setSequences(s0, s1)
+        runner = BandRunner(al, dist=dist, rank=rank, world=world, device=None, transport="p2p", prune_blocks=True)
+        best = runner.run(m, lim[rank], lim[rank + 1], n_total=n)
+        st = al.getStatistics()
+        gbest = tuple(runner.reduce_best(best))
+        al.close()
+        q.put((rank, gbest, runner.initial_bound, st["pruned_cells"], runner.restarts))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_seed_bound_travels_with_the_start_token_between_processes(pkg):
+    """two rank processes, one band each (ports through hipIpc on the shared GPU): band 0 runs the seed pass, band 1 receives
+    the value with its start token -- both begin with the same bound, and the chain's best is the seed's score on this pair"""
+    world, m, n = 2, 9000000, 8500000
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_seeded, args=(r, world, port, m, n, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=800) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0][2] is not None and res[0][2] == res[1][2], res
+    assert res[0][1] == res[1][1] and res[0][1][2] == res[0][2], res
+    assert sum(r[3] for r in res) > 0.6 * m * n and all(r[4] == 0 for r in res), res

@@ -213,3 +213,76 @@ def test_resume_continues_from_the_last_row_on_disk(pkg, oracle, tmp_path):
                      block_pruning=False)
     assert res["resumed_from"] == on_disk[-1]
     assert tuple(res["best"]) == tuple(CASE["best"])
+
+
+def test_queued_file_operations_keep_their_order(pkg, tmp_path):
+    """inside sra.async_files() rows, renames, truncations and the status file are carried out by one thread in the order
+    they were asked for: what is on disk afterwards is what the inline form leaves, a reader of a partition waits for
+    that partition's operations, and a status file never names a row that is not in place"""
+    sra = pkg.sra
+    cells = (np.arange(2 * 5000, dtype=np.int32).reshape(5000, 2) * 7) % 100003
+    seen = []
+
+    def build(area_dir, work):
+        area = sra.SpecialRowsArea(area_dir)
+        p = area.create_partition(0, 0, 4000, 4999)
+        st = sra.Status(work)
+        for row in (1000, 2000, 3000):
+            for j in range(0, 5000, 1024):
+                done = p.write(row, cells[j:j + 1024] + row)
+            assert done is True
+            st.stage, st.last_special_row = 1, row
+            st.save((row, row, row))
+        p.write(3500, cells[:100])                      # incomplete: closed by truncate(), renamed as it is
+        r = sra.SpecialRowReader(p, 2000)               # reads wait for the partition's queued operations
+        r.seek(5000)
+        buf = np.empty((5000, 2), dtype=np.int32)
+        assert r.read(buf, 5000) == 5000 and np.array_equal(buf[::-1], cells + 2000)
+        area.truncate_partition(p, 2500, 3999)          # rows 3000 and 3500 go, the others lose their last 1000 cells
+        seen.append(os.path.basename(p.path))
+        return p
+
+    os.makedirs(os.path.join(str(tmp_path), "wa"))
+    os.makedirs(os.path.join(str(tmp_path), "wb"))
+    with sra.async_files():
+        p = build(os.path.join(str(tmp_path), "a"), os.path.join(str(tmp_path), "wa"))
+        assert np.array_equal(p.read_row(1000), (cells + 1000)[:4000])
+    q = build(os.path.join(str(tmp_path), "b"), os.path.join(str(tmp_path), "wb"))   # the same, inline
+
+    def tree(d):
+        out = {}
+        for root, _, files in os.walk(d):
+            for fn in files:
+                out[os.path.relpath(os.path.join(root, fn), d)] = hashlib.sha256(open(os.path.join(root, fn), "rb").read()).hexdigest()
+        return out
+    assert seen[0] == seen[1] == "00000000.00000000.000009C4.00000F9F"
+    assert tree(os.path.join(str(tmp_path), "a")) == tree(os.path.join(str(tmp_path), "b")) and len(tree(os.path.join(str(tmp_path), "a"))) == 2
+    assert tree(os.path.join(str(tmp_path), "wa")) == tree(os.path.join(str(tmp_path), "wb"))
+    assert open(os.path.join(str(tmp_path), "wa", "status")).read() == "1\n3000\n3000 3000 3000\n"
+    assert p.rows == q.rows == [1000, 2000]
+
+
+def test_queued_file_operation_that_fails_is_reported(pkg, tmp_path):
+    sra = pkg.sra
+    area = sra.SpecialRowsArea(os.path.join(str(tmp_path), "a"))
+    os.makedirs(area.directory)
+    with pytest.raises(RuntimeError, match="queued file operation failed"):
+        with sra.async_files():
+            p = area.create_partition(0, 0, 100, 9)
+            p.write(50, np.zeros((10, 2), dtype=np.int32))
+            sra._files.submit(p, os.remove, os.path.join(p.path, "no such row"))
+            sra.drain()
+    sra.drain()                                          # the queue is usable again
+    with sra.async_files():
+        p.write(60, np.ones((10, 2), dtype=np.int32))
+    assert np.array_equal(p.read_row(60), np.ones((10, 2), dtype=np.int32))
+
+
+def test_file_operations_inline_on_request(pkg, tmp_path, monkeypatch):
+    """MI355SW_SRA_SYNC=1: no thread, every operation at once"""
+    sra = pkg.sra
+    monkeypatch.setenv("MI355SW_SRA_SYNC", "1")
+    with sra.async_files():
+        p = sra.SpecialRowsPartition(os.path.join(str(tmp_path), "a"), 0, 0, 100, 9)
+        assert p.write(50, np.zeros((10, 2), dtype=np.int32)) is True
+        assert os.listdir(p.path) == ["00000032"] and not sra._files.pending
