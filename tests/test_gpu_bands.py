@@ -557,7 +557,7 @@ def test_chain_in_one_process_on_one_device(pkg, recurrence):
 def test_chain_takes_its_first_bound_from_the_diagonal_seed(pkg, recurrence):
     """A chain that prunes starts from the diagonal seed of the WHOLE matrix (bands.chain_seed_bound -> mi355sw_seed_bound):
     three bands of a 9 M x 8.5 M related pair side by side on cuda:0, with and without it -- the same answer, the seed's value
-    is the answer itself on this pair (local) or a lower bound of it (global), and far more of the matrix goes."""
+    is the score of an alignment that exists (local) or a lower bound of H[m][n] (global), and far more of the matrix goes."""
     from masa_cudalign_amd.bands import InProcessChain, band_limits
     world, m, n = 3, 9000000, 8500000
     s0, s1 = pkg.seqgen.related_pair(m, n, cfg=5)
@@ -574,7 +574,8 @@ def test_chain_takes_its_first_bound_from_the_diagonal_seed(pkg, recurrence):
         assert out[False][0] == out[True][0], out
         assert out[False][2] is None and out[True][2] is not None and out[False][3] == out[True][3] == 0
         if recurrence == "sw":
-            assert out[True][2] == out[True][0][2], out                 # the staircase holds the whole alignment of this pair
+            # (the score of an alignment that exists: here the longest stretch the +-64 Ki band could follow, 82 % of the best)
+            assert 0.5 * out[True][0][2] < out[True][2] <= out[True][0][2], out
         else:
             assert out[True][2] <= out[True][0][2] and out[True][2] > out[True][0][2] - 100000, out
         assert out[True][1] > out[False][1] + 0.15 and out[True][1] > 0.6, out
@@ -615,7 +616,7 @@ def _worker_seeded(rank, world, port, m, n, q):
 @pytest.mark.timeout(900)
 def test_seed_bound_travels_with_the_start_token_between_processes(pkg):
     """two rank processes, one band each (ports through hipIpc on the shared GPU): band 0 runs the seed pass, band 1 receives
-    the value with its start token -- both begin with the same bound, and the chain's best is the seed's score on this pair"""
+    the value with its start token -- both begin with the same bound, below the chain's best"""
     world, m, n = 2, 9000000, 8500000
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -628,5 +629,5 @@ def test_seed_bound_travels_with_the_start_token_between_processes(pkg):
         p.join(timeout=60)
         assert p.exitcode == 0
     assert res[0][2] is not None and res[0][2] == res[1][2], res
-    assert res[0][1] == res[1][1] and res[0][1][2] == res[0][2], res
+    assert res[0][1] == res[1][1] and 0.5 * res[0][1][2] < res[0][2] <= res[0][1][2], res
     assert sum(r[3] for r in res) > 0.6 * m * n and all(r[4] == 0 for r in res), res

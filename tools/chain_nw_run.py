@@ -29,11 +29,13 @@ def main():
     try:
         for a in als:
             a.setSequences(s0, s1)
-        chain = InProcessChain(als, prune_blocks=True)
+        # CHAIN_SEED=0: without the diagonal seed of the whole matrix (round 4 before mi355sw_seed_bound)
+        chain = InProcessChain(als, prune_blocks=True, seed_bound=os.environ.get("CHAIN_SEED", "1") != "0")
         t0 = time.time()
         best, stats = chain.run(m, band_limits(n, [1] * bands), **kw)
         dt = time.time() - t0
         res["chain"] = {"h_last_cell": best[2], "seconds": dt, "gcups_m_n": float(m) * n / dt / 1e9, "restarts": chain.restarts,
+                        "initial_bound": chain.initial_bound, "seed_ms": stats[0].get("seed_ms"),
                         "pruned_fraction": sum(s["pruned_cells"] for s in stats) / (float(m) * n),
                         "band": [{"columns": s["cells"] // m, "kernel_ms": s["kernel_ms"], "pruned_fraction": s["pruned_cells"] / float(s["cells"]),
                                   "kernel": s["kernel"], "strip_rows": s["strip_rows"], "wait_ms": s["wait_ms"]} for s in stats]}
