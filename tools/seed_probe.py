@@ -11,7 +11,7 @@ from masa_cudalign_amd.bands import BandRunner  # noqa: E402
 m, n, kind = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
 cfg = int(sys.argv[4]) if len(sys.argv) > 4 else 5
 s0, s1 = pkg.seqgen.related_pair(m, n, cfg=cfg)
-al = pkg.MI355Aligner(device=0)
+al = pkg.MI355Aligner(device=0, rows_per_lane=int(os.environ.get("ROWS_PER_LANE", "0")))
 al.setSequences(s0, s1)
 part = pkg.Partition(0, 0, m, n)
 t0 = time.time()
