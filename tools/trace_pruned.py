@@ -13,3 +13,12 @@ for lo, hi in ((0, S // 8), (S // 8, S // 2), (S // 2, 7 * S // 8), (7 * S // 8,
     d = dur[lo:hi]
     lag = np.diff(us[lo:hi, 1]) if hi - lo > 2 else np.zeros(1)
     print("strips %6d..%6d: lifetime mean %.1f ms (p10 %.1f, p90 %.1f); end-to-end lag mean %.1f us" % (lo, hi, d.mean(), np.percentile(d, 10), np.percentile(d, 90), lag.mean()))
+# chunk 1000 (column 64 000) lies left of the band for every strip below row ~100 000: where the general body handled it (and
+# not a fast-forward run) its four phases are those of a skipped slab
+ph = t[S // 4:S, 3]
+ph = ph[ph != 0]
+if len(ph):
+    parts = [((ph >> sh) & 0xffff) / 100.0 for sh in (0, 16, 32, 48)]
+    tot = sum(parts)
+    print("chunk 1000 of %d strips below the first quarter, handled by the chunk body: input %.2f + stage %.2f + compute %.2f + tail %.2f = %.2f us (p10 %.2f, p90 %.2f)"
+          % (len(ph), parts[0].mean(), parts[1].mean(), parts[2].mean(), parts[3].mean(), tot.mean(), np.percentile(tot, 10), np.percentile(tot, 90)))
