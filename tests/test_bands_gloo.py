@@ -81,6 +81,9 @@ class OracleStreamEngine:
         self.prune = bool(prune_blocks)
         self.share = bool(share_best) and not os.environ.get("MI355SW_NO_SHARED_BEST")
         self.hint = -o.INF
+        if kw.get("initial_bound") is not None:       # mi355sw_stream_params.initial_bound: what the bound starts from
+            self.hint = int(kw["initial_bound"])
+        self.initial_bound_seen = kw.get("initial_bound")
         self.own_best = -o.INF
         self.pruned_blocks = self.total_blocks = 0
         self.part, self.rec = part, recurrence_type
@@ -637,3 +640,72 @@ def test_band_stage1_leaves_the_area_of_a_forked_node(pkg, oracle, transport, tm
     same special-row files, border markers and tee'd boundary column, byte for byte."""
     rows = check_area_against_split_reference(pkg, oracle, tmp_path, 3000, 3300, 3, _worker_area, transport)
     assert rows >= 9
+
+
+class SeedingOracleEngine(OracleStreamEngine):
+    """... with mi355sw_seed_bound: here simply the best local score itself (the score of an alignment that exists)"""
+    seed_calls = 0
+
+    def seedBound(self, part, recurrence_type=1):
+        self.seed_calls += 1
+        ref = self.o.stage1(self.s0[part.i0:part.i1], self.s1[part.j0:part.j1])
+        return int(ref["best"][2])
+
+
+def _worker_seed(rank, world, port, m, n, transport, q):
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as graft
+    pkg = graft.load_package()
+    oracle = graft.load_oracle()
+    from masa_cudalign_amd import bands
+    bands.SEED_MIN_EXTENT = 0                  # the test matrix is tiny
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        s0, s1 = pkg.seqgen.related_pair(m, n, cfg=41)
+        lim = bands.band_limits(n, [1] * world)
+        out = {}
+        for seed in (False, True):
+            eng = SeedingOracleEngine(oracle, s0, s1, seg=256)
+            runner = bands.BandRunner(eng, dist=dist, rank=rank, world=world, device=None, segment_rows=300, transport=transport,
+                                      prune_blocks=True, seed_bound=seed)
+            if transport == "p2p":
+                assert runner.probe_p2p(m)
+            best = runner.run(m, lim[rank], lim[rank + 1], n_total=n)
+            out[seed] = dict(best=tuple(runner.reduce_best(best)), pruned=eng.pruned_blocks, total=eng.total_blocks, calls=eng.seed_calls,
+                             bound=runner.initial_bound, seen=eng.initial_bound_seen)
+            dist.barrier()
+            eng.portClose()
+        q.put((rank, out))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("transport", ["host", "p2p"])
+def test_seed_bound_travels_with_the_start_token(pkg, oracle, transport):
+    """A pruning chain starts from the diagonal seed of the whole matrix (bands.chain_seed_bound): band 0 alone asks its engine
+    for it, the value reaches every band with the ordered-start token and goes into its streamBegin(initial_bound=...); same
+    best cell, and every band -- the first one above all, which otherwise starts from nothing -- prunes at least as much."""
+    m, n, world = 1500, 1800, 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_seed, args=(r, world, port, m, n, transport, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=240) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    s0, s1 = pkg.seqgen.related_pair(m, n, cfg=41)
+    ref = oracle.stage1(s0, s1)
+    want = (ref["best"][0] - 1, ref["best"][1] - 1, ref["best"][2])
+    for r in range(world):
+        assert res[r][False]["best"] == res[r][True]["best"] == want, r
+        assert res[r][False]["bound"] is None and res[r][False]["seen"] is None and res[r][False]["calls"] == 0, r
+        assert res[r][True]["bound"] == res[r][True]["seen"] == want[2], r
+        assert res[r][True]["calls"] == (1 if r == 0 else 0), r
+        assert res[r][True]["pruned"] >= res[r][False]["pruned"], r
+    assert res[0][True]["pruned"] > res[0][False]["pruned"]
