@@ -114,3 +114,30 @@ def test_crosspoint_array_writer_equals_the_object_writer(pkg, tmp_path):
     assert open(a, "rb").read() == open(b, "rb").read()
     save_array(b, [tuple(int(x) for x in r) for r in pts[:3]])            # a list of tuples is taken as well
     assert open(b).read().split()[1] == "%d,%d,%d,%d" % tuple(pts[0])
+
+
+def test_chain_seed_bound_only_where_the_seed_applies(pkg, monkeypatch):
+    """bands.chain_seed_bound asks the engine for the diagonal seed of the whole matrix only for large matrices whose borders
+    are the recurrence's own (zeroes for a local alignment, gap penalties from the origin for a global one)"""
+    from masa_cudalign_amd import bands
+
+    class Eng:
+        asked = []
+
+        def seedBound(self, part, rec):
+            self.asked.append(((part.i0, part.j0, part.i1, part.j1), rec))
+            return 4242
+
+    e, big = Eng(), 9 << 20
+    Z, G, C = pkg.INIT_WITH_ZEROES, pkg.INIT_WITH_GAPS, pkg.INIT_WITH_CUSTOM_DATA
+    assert bands.chain_seed_bound(e, big, big, pkg.SMITH_WATERMAN, Z, Z) == 4242
+    assert bands.chain_seed_bound(e, big, big, pkg.NEEDLEMAN_WUNSCH, G, G) == 4242
+    assert e.asked == [((0, 0, big, big), pkg.SMITH_WATERMAN), ((0, 0, big, big), pkg.NEEDLEMAN_WUNSCH)]
+    for args in ((1 << 20, big, pkg.SMITH_WATERMAN, Z, Z), (big, 1 << 20, pkg.SMITH_WATERMAN, Z, Z),       # too small
+                 (big, big, pkg.SMITH_WATERMAN, G, Z), (big, big, pkg.NEEDLEMAN_WUNSCH, Z, G),               # other borders
+                 (big, big, pkg.NEEDLEMAN_WUNSCH, G, C)):
+        assert bands.chain_seed_bound(e, *args) is None, args
+    assert bands.chain_seed_bound(object(), big, big, pkg.SMITH_WATERMAN, Z, Z) is None                       # an engine without the entry point
+    monkeypatch.setenv("MI355SW_NO_DIAGONAL_SEED", "1")
+    assert bands.chain_seed_bound(e, big, big, pkg.SMITH_WATERMAN, Z, Z) is None
+    assert len(e.asked) == 2
