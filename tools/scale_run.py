@@ -234,6 +234,54 @@ def case_c5band(out, m=249000000, n=28500000, k_rows=400, k_cols=48):
     assert out["check"]["ok"], out["check"]
 
 
+def case_c5band_seeded(out, m=249000000, n=28500000, n_total=228000000, k_rows=100):
+    """band 0 of C5 as it runs in the pruning chain since the chain has a seed: the diagonal seed pass over the WHOLE
+    249 M x 228 M matrix first (mi355sw_seed_bound: what band 0 does before the chain starts, bands.chain_seed_bound), then
+    the band with block pruning against that lower bound of H[249 M][228 M] and the extents of the whole matrix.  One GPU's
+    share of BASELINE config 5 as worded, seed included.  Pinned on: the first k_rows cells of the last column against the
+    oracle's sweep of those rows (equal or skipped); the seed is a lower bound that some global alignment reaches (nothing can check H[m][n]
+    of 5.7e16 cells here; at a quarter of the size it IS H[m][n]: profiles/r04_nw_c5_quarter_62Mx57M_final.json)."""
+    from masa_cudalign_amd.engine import NEEDLEMAN_WUNSCH, INIT_WITH_GAPS
+    t0 = time.time()
+    s0, s1 = pkg.seqgen.related_pair(m, n_total, cfg=15)
+    out["generate_s"] = time.time() - t0
+    al = pkg.MI355Aligner(device=0)
+    al.setSequences(s0, s1)
+    t0 = time.time()
+    bound = al.seedBound(pkg.Partition(0, 0, m, n_total), NEEDLEMAN_WUNSCH)
+    out["seed_s"] = time.time() - t0
+    out["seed_bound"] = bound
+    print(json.dumps({"seed_s": out["seed_s"], "seed_bound": bound}), flush=True)
+    part = pkg.Partition(0, 0, m, n)
+    keep = {}
+
+    def borders(al):
+        col = al.streamReadColumn(0, k_rows)
+        keep["col_head"] = col.copy()
+        return None
+
+    r = run(al, part, before_end=borders, recurrence_type=NEEDLEMAN_WUNSCH, first_row_init_type=INIT_WITH_GAPS,
+            first_column_init_type=INIT_WITH_GAPS, want_last_column=True, track_best=False, prune_blocks=True, prune_rows=m, prune_cols=n_total,
+            initial_bound=bound)
+    al.close()
+    out.update(r)
+    out["band_seconds_with_seed"] = out["seed_s"] + r["kernel_ms"] / 1e3
+    out["band_gcups_mn_with_seed"] = float(m) * n / out["band_seconds_with_seed"] / 1e9
+    oracle = g.load_oracle()
+    top = oracle.stage1(s0[:k_rows], s1[:n], recurrence=NEEDLEMAN_WUNSCH, first_row_type=INIT_WITH_GAPS,
+                        first_col_type=INIT_WITH_GAPS, want_last_col=True, best_mode=oracle.BEST_LAST_CELL)
+    oc = np.asarray(top["last_col"])
+    oc = oc[-k_rows:] if len(oc) > k_rows else oc
+    # (with a bound this tight the top of the last column -- row 0..k_rows at column n, far off the diagonal -- is itself skipped:
+    #  lower bounds of the oracle's cells, equal where they were computed)
+    kh, oh = keep["col_head"][:, 0].astype(np.int64), oc[:, 0].astype(np.int64)
+    out["check"] = {"last_column_head_rows": k_rows, "last_column_head_lower_bound": bool((kh <= oh).all()),
+                    "last_column_head_equal_or_skipped": bool(((kh == oh) | (kh <= -900000000)).all()),
+                    "a_bound_was_found": bound is not None, "most_of_the_band_skipped": r["pruned_fraction"] > 0.5}
+    out["check"]["ok"] = all(v for v in out["check"].values() if isinstance(v, bool))
+    assert out["check"]["ok"], out["check"]
+
+
 def case_c5band_pruned(out, m=249000000, n=28500000, n_total=228000000, k_rows=400):
     """band 0 of C5 once more, as it runs in the pruning chain (round 4): block pruning ON against the lower bound of
     H[249 M][228 M] -- the bound looks at all 228 M columns (prune_cols), the band's own cells supply it.  Alone, the band
@@ -351,6 +399,10 @@ if __name__ == "__main__":
         case_nw_tall(out)
     elif case == "nwtallsmall":
         case_nw_tall(out, 40000000, 50000)
+    elif case == "c5band_seeded":
+        case_c5band_seeded(out)
+    elif case == "c5band_seeded_small":
+        case_c5band_seeded(out, 12000000, 1400000, 11000000, 100)
     elif case == "c5band_pruned":
         case_c5band_pruned(out)
     elif case == "c5band_pruned_small":
