@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Stage-1 GCUPS bench (BASELINE.json metric) for the MI355X strip-wavefront engine.
 
-    python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W        (any N: for N > 1 it starts its own ranks, see self_launch)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -119,6 +119,100 @@ def cpu_baseline_mt(pkg):
             "sample": "%dx%d unrelated SW stage-1, oracle/sw_oracle.c on %d threads, best=%s" % (side, side, cores, list(r["best"]))}
 
 
+def self_launch(argv, gpus):
+    """`python3 bench.py --gpus N` with N > 1 and no rank environment: start the ranks ourselves.
+
+    The reference forks its nodes BEFORE any device call from one command line (M/libmasa/libmasa.cpp:540-642, device
+    selection per node X/cuda_util.cpp:191-257); here the parent -- which has imported nothing that touches the GPU --
+    starts `python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py <same arguments>` as a CHILD process
+    (never an exec), relays rank 0's JSON line to its own stdout and everything else to stderr, and returns the child's
+    exit code.  MI355SW_BENCH_TIMEOUT_S (default 3300) bounds the child: on a time-out its whole process group is
+    terminated and the exit code is 124."""
+    import signal
+    import socket
+    import threading
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:       # a free rendezvous port on the loopback
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % gpus,
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env["MI355SW_BENCH_LAUNCHER"] = "self"
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: the column ports between the rank processes need it
+    env.setdefault("OMP_NUM_THREADS", "1")
+    timeout = float(os.environ.get("MI355SW_BENCH_TIMEOUT_S", "3300"))
+    sys.stderr.write("[bench] starting %d ranks: %s\n" % (gpus, " ".join(cmd)))
+    sys.stderr.flush()
+    child = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=None, env=env, start_new_session=True)
+    lines = []
+
+    def relay():
+        for raw in child.stdout:
+            text = raw.decode(errors="replace")
+            is_line = False
+            if text.lstrip().startswith("{"):
+                try:
+                    is_line = "metric" in json.loads(text) or "launch_check" in json.loads(text)
+                except ValueError:
+                    pass
+            if is_line:
+                lines.append(text)
+                sys.stdout.write(text)
+                sys.stdout.flush()
+            else:
+                sys.stderr.write(text)
+                sys.stderr.flush()
+
+    th = threading.Thread(target=relay, daemon=True)
+    th.start()
+    try:
+        rc = child.wait(timeout=timeout)
+    except subprocess.TimeoutExpired:
+        sys.stderr.write("[bench] the ranks did not finish within %.0f s: terminating them\n" % timeout)
+        for sig, grace in ((signal.SIGTERM, 10.0), (signal.SIGKILL, 10.0)):
+            try:
+                os.killpg(child.pid, sig)           # the child leads its own process group (start_new_session)
+            except ProcessLookupError:
+                break
+            try:
+                child.wait(timeout=grace)
+                break
+            except subprocess.TimeoutExpired:
+                continue
+        th.join(5.0)
+        return 124
+    th.join(30.0)
+    if rc == 0 and not lines:
+        sys.stderr.write("[bench] the ranks ended without a result line\n")
+        return 1
+    return rc
+
+
+def launch_check(args):
+    """--launch-check: what the launcher needs to work, without a GPU -- every rank joins a gloo group over the rendezvous it
+    was handed, the ranks add up their numbers, rank 0 prints one line.  (CPU test of the self-launch branch.)"""
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    t = torch.tensor([rank + 1], dtype=torch.int64)
+    if world > 1:
+        dist.all_reduce(t)
+    if args.launch_check_sleep > 0:
+        time.sleep(args.launch_check_sleep)
+    if rank == 0:
+        print(json.dumps({"launch_check": True, "world": world, "gpus": args.gpus, "sum_of_ranks": int(t.item()),
+                          "launcher": os.environ.get("MI355SW_BENCH_LAUNCHER", "external"),
+                          "master": "%s:%s" % (os.environ.get("MASTER_ADDR"), os.environ.get("MASTER_PORT"))}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -143,7 +237,17 @@ def main():
     ap.add_argument("--no-target-shape", action="store_true", help="N = 1: skip the 228 M-row north-star-height step")
     ap.add_argument("--no-single-reference", action="store_true",
                     help="N > 1: skip rank 0's untimed run of ONE GPU's share of the cells (tall*size x size) alone")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="only check the launcher: the ranks meet over gloo, rank 0 prints one line (runs without a GPU)")
+    ap.add_argument("--launch-check-sleep", type=float, default=0.0, help=argparse.SUPPRESS)
     args = ap.parse_args()
+
+    # N > 1 from a plain `python3 bench.py --gpus N`: the ranks are started here, as a child process, before anything that
+    # initialises the GPU has been imported (self_launch)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(sys.argv[1:], args.gpus)
+    if args.launch_check:
+        return launch_check(args)
 
     import torch
     import torch.distributed as dist
@@ -156,8 +260,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N>1 with torch.distributed.run (one rank per GPU)")
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: one rank per GPU (python3 bench.py --gpus N starts them itself)" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; the engine has no CPU fallback")
     # MI355SW_BENCH_REHEARSAL=1: run the N>1 path on a ONE-GPU box (every rank on cuda:0, gloo instead of RCCL for
@@ -416,6 +519,8 @@ def main():
                        "reserved_cus": args.reserve_cus,
                        "kernel": {2: "pk16", 1: "int32-profile", 0: "int32-generic"}[st["profile_kernel"]],
                        "comm": comm if world > 1 else "none", "comm_note": comm_note,
+                       # who started the ranks: "self" = python3 bench.py --gpus N (self_launch), "external" = a torchrun around it
+                       "launcher": (os.environ.get("MI355SW_BENCH_LAUNCHER", "external") if world > 1 else "none"),
                        # does the boundary column cross a GPU-to-GPU link?  Only with column ports between different
                        # devices; the host transport (pinned columns + gloo over loopback) and a rehearsal do not
                        "xgmi": bool(world > 1 and comm in ("p2p", "p2p-attach") and not rehearse),
@@ -626,4 +731,4 @@ def _reduce_cpu(dist, best, world, device):
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

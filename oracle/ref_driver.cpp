@@ -252,7 +252,7 @@ int main(int argc, char** argv) {
     int bh = 1024, bw = 1024;
     int split_count = 0, split_step = 0;
     int max_alignments = 1;
-    std::string flush_url, load_url;
+    std::string flush_url, load_url, shared_dir;
     bool gpu_stage4 = false;
     bool dump_blocks = false;
     bool do_fork = false;
@@ -283,6 +283,7 @@ int main(int argc, char** argv) {
         else if (!strncmp(s, "--reverse=", 10)) parse_seq_flags(s + 10, reverse_seq);
         else if (!strncmp(s, "--complement=", 13)) parse_seq_flags(s + 13, complement_seq);
         else if (!strncmp(s, "--reverse-complement=", 21)) { parse_seq_flags(s + 21, complement_seq); reverse_seq[0] = complement_seq[0]; reverse_seq[1] = complement_seq[1]; }
+        else if (!strncmp(s, "--shared-dir=", 13)) shared_dir = s + 13;        /* libmasa.cpp --shared-dir: AlignerPool's message directory (Job.cpp:156-158) */
         else if (!strcmp(s, "--dump-blocks")) dump_blocks = true;              /* libmasa.cpp:1082: best score of every block -> <work>/pruning_dump.txt */
         else if (!strcmp(s, "--gpu-stage4")) gpu_stage4 = true;               /* product stage 4 instead of MASA-Core's */
         else if (!strcmp(s, "--fork")) do_fork = true;                       /* weights from IAligner::getForkWeights */
@@ -324,6 +325,7 @@ int main(int argc, char** argv) {
     job->block_pruning = pruning;
     job->dump_blocks = dump_blocks;
     job->setWorkPath(work);
+    if (!shared_dir.empty()) job->setSharedPath(shared_dir);
     job->stage4_maximum_partition_size = 16;
     job->stage4_strategy = STAGE_4_STRATEGY_OPTIMIZED;
     job->stage6_output_format = 0;
