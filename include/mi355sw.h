@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define MI355SW_ABI_VERSION 6
+#define MI355SW_ABI_VERSION 7
 
 /* M/libmasa/libmasaTypes.hpp:35-41  cell_t {int h; union{int f; int e;};} 8-byte aligned */
 typedef struct { int32_t h; int32_t f; } mi355sw_cell;
@@ -52,13 +52,18 @@ typedef struct { int32_t i0, j0, i1, j1; } mi355sw_partition;
 #define MI355SW_ETRACEBACK (-8)  /* stage 4: no column of a partition matches its score difference (the crosspoints do
                                     not lie on one optimal alignment of these sequences)                          */
 #define MI355SW_ETOOLARGE (-9)   /* stage 4: a partition beyond the reference's own limit (131072 columns)         */
+#define MI355SW_EBOUND (-10)     /* a pruning run ended BELOW the bound it started from (mi355sw_stream_params.initial_bound): the
+                                    bound was not the score of an alignment that exists -- the optimum may have been pruned
+                                    away with it, so the result is void.  The reference has no such check (a wrong best
+                                    score loaded by Status::load, sw_stage1.cpp:210-217, silently prunes). */
 #define MI355SW_EOVERFLOW16 (-7) /* packed 16-bit kernel left its exact range: rerun with force_int32
                                     (mi355sw_align_partition and mi355sw_process_block do that by themselves;
                                     the streaming form reports it from poll/end, rows handed out before are exact) */
 
 typedef struct mi355sw_handle mi355sw_handle;
 
-/* Extension parameters; replaces X/CUDAlignerParameters.cpp:33-110 (--gpu, --blocks). */
+/* Extension parameters; replaces X/CUDAlignerParameters.cpp:33-110 (--gpu, --blocks).  The library reads NO environment
+ * variable: every switch is a field here (ABI 7; the Python front maps its MI355SW_* variables onto them, engine.py). */
 typedef struct {
     int32_t device;          /* HIP ordinal, -1 = current device (reference: --gpu)                 */
     int32_t rows_per_lane;   /* R in {4,8,12,16,24,32} (12/24/32: packed kernel only); strip height = 64*R (reference: THREADS_COUNT*ALPHA);
@@ -74,7 +79,15 @@ typedef struct {
                                     AbstractDiagonalAligner.cpp:392-403); its only consumer is --dump-blocks
                                     (AlignerManager.cpp:418-423, BlocksFile.cpp).  Costs a second sweep of the
                                     partition, as a chain of W-column bands.  0 = off. */
-    int32_t reserved_;
+    int32_t verbosity;       /* MI355SW_V_* bits: diagnostics on stderr (0 = none) */
+    double wait_seconds;     /* wall-time budget of the in-kernel waits on data somebody else delivers (the host's first
+                                column, the previous band's GPU); 0 = 3600 */
+    int32_t fault_overflow_strip_plus1; /* TEST KNOB: strip (k - 1) of every packed launch reports an overflow it did not have, so
+                                that the int32 rerun / replay paths can be exercised; 0 = off */
+    int32_t stream_priority; /* 0 = the kernel stream gets the highest priority (default), 1 = normal, 2 = lowest */
+    const char* trace_path;  /* per-strip timing records of every stream are written to this file (tools/trace_hops.py); NULL = off.
+                                The string is copied. */
+    int64_t reserved_[4];    /* zero */
 } mi355sw_config;
 #define MI355SW_F_FORCE_GENERIC_COMPARE 1   /* raw byte compare kernels even if a profile fits */
 #define MI355SW_F_FORCE_INT32 2             /* never use the packed 16-bit SW kernel */
@@ -82,6 +95,20 @@ typedef struct {
                                                bound then only grows with what the sweep itself finds, as in the reference.
                                                For callers that want SEVERAL alignments (--max-alignments > 1): a strong
                                                first bound prunes the weaker ones away sooner than the reference's would. */
+#define MI355SW_F_NO_SEED_PASS 8            /* no throw-away pass that warms the running best before the main launch, no probe */
+#define MI355SW_F_NO_PRUNE_PROBE 16         /* a run that asks for pruning gets the pruning kernels whatever the probe of the
+                                               pair says (see mi355sw_stream_begin) */
+#define MI355SW_F_TWO_PHASE 32              /* value-only tracking + exact pass of the winning strip at every size (default:
+                                               from 32 Mi rows) */
+#define MI355SW_F_NO_MIXED 64               /* never two strip heights in one launch */
+#define MI355SW_F_NO_SHARED_BEST 128        /* share_best streams keep their running best to themselves */
+#define MI355SW_F_NO_BATCH 256              /* mi355sw_align_partitions runs its partitions one by one */
+#define MI355SW_F_NO_HOST_COUNTER 512       /* the kernel does not mirror its strip counter into host memory (measurements) */
+#define MI355SW_V_MESSAGES 1                /* one line per noteworthy event (overflow reruns, the diagonal seed, ...) */
+#define MI355SW_V_JOBS 2                    /* timing of every mi355sw_align_partition job */
+#define MI355SW_V_SEED_TILES 4              /* every tile of the diagonal seed */
+#define MI355SW_V_BATCH 8                   /* progress of mi355sw_align_partitions */
+#define MI355SW_V_DEBUG_WORDS 16            /* kernels keep debug words, mi355sw_progress shows them */
 
 /* aligner_capabilities_t, M/libmasa/capabilities.hpp:59-225 (same fields, int32 instead of bool) */
 typedef struct {
@@ -161,6 +188,9 @@ typedef struct {
 
 /* ---- life cycle: IAligner::initialize/finalize (IAligner.hpp:186,226; X/CUDAligner.cpp:137-174) ---- */
 int mi355sw_create(const mi355sw_config* config, mi355sw_handle** out);
+/* every field of `config` but `device` and `stream_priority` again, for the calls that follow (no stream may be active):
+ * what a MASA extension does when its parameters change between stages (IAlignerParameters, X/CUDAlignerParameters.cpp) */
+int mi355sw_configure(mi355sw_handle* h, const mi355sw_config* config);
 void mi355sw_destroy(mi355sw_handle* h);
 const char* mi355sw_last_error(mi355sw_handle* h);
 int mi355sw_abi_version(void);
@@ -266,7 +296,11 @@ typedef struct {
                                            score of a local alignment that exists (the best of a run that is being resumed,
                                            of another node: Status::load / AlignerPool::getBestNodeScore in the reference), or
                                            for a global alignment a lower bound of the last cell's score.  Without it, large
-                                           matrices get one from the diagonal seed pass (mi355sw_stats.seed_ms). */
+                                           matrices get one from the diagonal seed pass (mi355sw_stats.seed_ms).
+                                           A value NO alignment reaches would prune the optimum away: a stream that covers
+                                           its whole super-partition checks what it found against the bound it was given and
+                                           mi355sw_stream_end returns MI355SW_EBOUND when it ended below it (chains of bands:
+                                           the driver checks the chain's result, bands.py). */
 } mi355sw_stream_params;
 
 int mi355sw_stream_begin(mi355sw_handle* h, const mi355sw_partition* partition, const mi355sw_stream_params* p);

@@ -83,6 +83,17 @@ def chain_seed_bound(engine, m, n, recurrence, first_row_init_type, first_col_in
     return engine.seedBound(Partition(0, 0, m, n), recurrence)
 
 
+def check_chain_bound(score, bound):
+    """A pruning chain must end at or above the bound it started from (the diagonal seed's, a caller's): that bound is the score of
+    an alignment that exists / a lower bound of H[m][n], and slabs that can still reach it are computed.  A chain that ends below
+    was given a bound no alignment reaches -- its optimum may have been pruned away, the result is void.  One stream checks this
+    itself (MI355SW_EBOUND, mi355sw_stream_end); a band of a chain cannot (the best may be another band's)."""
+    from .engine import AlignerError
+    if bound is not None and score is not None and int(score) < int(bound):
+        raise AlignerError("EBOUND: the chain ended at %d, below the bound %d its pruning started from -- no alignment reaches that "
+                           "bound, the result is void" % (int(score), int(bound)))
+
+
 class BandRunner:
     """Runs one band of the chain on this rank.  `dist` is torch.distributed (already initialised) or an object
     with send/recv/all_gather, or None for a single band.  All ranks must call run() with the same m.
@@ -113,6 +124,7 @@ class BandRunner:
         self.inbound_crc = None      # crc32 of the inbound boundary column of the last run(digest_inbound=True)
         self.special_rows = []       # DP rows of the special rows the last run handed to its sink
         self.hints = 0               # best-score hints this band took from the others in the last run (host transport)
+        self.stall_abort_s = None    # seconds without progress after which run() gives up (None: MI355SW_BAND_STALL_S, default 900)
         # Block pruning over a chain of bands needs the best of the WHOLE matrix (the reference switches pruning off
         # when it forks, libmasa.cpp:1318-1321).  Between GPUs the kernels share it through the column ports; on the
         # host transport a side thread does, with one small all_reduce(MAX) every few milliseconds on its own group.
@@ -198,8 +210,10 @@ class BandRunner:
         if self.transport != "p2p":
             return True
         from .engine import AlignerError
-        saved = {k: os.environ.get(k) for k in ("MI355SW_WAIT_S", "MI355SW_BAND_STALL_S")}
-        os.environ["MI355SW_WAIT_S"] = os.environ["MI355SW_BAND_STALL_S"] = "%g" % budget_s
+        # the check's time budget: the engine's in-kernel waits (mi355sw_config.wait_seconds) and this driver's stall limit
+        saved_wait, saved_stall = self.engine._opts["wait_seconds"], self.stall_abort_s
+        self.engine.configure(wait_seconds=budget_s)
+        self.stall_abort_s = budget_s
         got = {}
         try:
             for transport in ("p2p", "host"):
@@ -224,11 +238,11 @@ class BandRunner:
             return all_min(same) == 1
         finally:
             self.transport = "p2p"
-            for k, v in saved.items():
-                if v is None:
-                    os.environ.pop(k, None)
-                else:
-                    os.environ[k] = v
+            self.stall_abort_s = saved_stall
+            try:
+                self.engine.configure(wait_seconds=saved_wait)
+            except AlignerError:            # (a stream the check left active: the caller closes the engine)
+                self.engine._opts["wait_seconds"] = saved_wait
 
     def run(self, m, j0, j1, recurrence=SMITH_WATERMAN, track_best=True, first_row_init_type=INIT_WITH_ZEROES,
             first_col_init_type=INIT_WITH_ZEROES, poll_sleep=0.0005, want_last_row=False, before_end=None,
@@ -454,7 +468,7 @@ class BandRunner:
         # segments sent), one per second with MI355SW_BAND_DEBUG=1; after MI355SW_BAND_STALL_S seconds (default
         # 900) without progress the band gives up instead of hanging its neighbours for ever
         debug = os.environ.get("MI355SW_BAND_DEBUG") == "1"
-        stall_abort = float(os.environ.get("MI355SW_BAND_STALL_S", "900"))
+        stall_abort = self.stall_abort_s if self.stall_abort_s is not None else float(os.environ.get("MI355SW_BAND_STALL_S", "900"))
         t_dbg = t_prog = time.time()
         seen = (-1, -1)
         rows_done, fin = 0, False
@@ -559,7 +573,10 @@ class BandRunner:
         t = torch.tensor(list(best), dtype=torch.int64, device=self.device if self.device is not None else "cpu")
         out = [torch.empty_like(t) for _ in range(self.world)]
         self.dist.all_gather(out, t)
-        return canonical_best([tuple(int(x) for x in o.tolist()) for o in out])
+        best = canonical_best([tuple(int(x) for x in o.tolist()) for o in out])
+        if self.prune_blocks:
+            check_chain_bound(best[2], self.initial_bound)
+        return best
 
 
 class InProcessChain:
@@ -642,6 +659,8 @@ class InProcessChain:
                     bests.append(b)
                     stats.append(als[k].getStatistics())
                 best = canonical_best(bests) if sw else (m - 1, n - 1, h_last)
+                if self.prune_blocks:
+                    check_chain_bound(best[2], self.initial_bound)
                 return best, stats
             except AlignerError as e:
                 for k in begun:                            # stop whatever is running, then the whole chain again on the int32 kernels

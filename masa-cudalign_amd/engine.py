@@ -21,7 +21,37 @@ NEEDLEMAN_WUNSCH, SMITH_WATERMAN = 0, 1
 INIT_WITH_ZEROES, INIT_WITH_GAPS, INIT_WITH_CUSTOM_DATA, INIT_WITH_GAPS_OPENED = 0, 1, 2, 3
 
 ERRORS = {-1: "EINVAL", -2: "EHIP", -3: "ENOGPU", -4: "ENOMEM", -5: "ETIMEOUT", -6: "ESTATE", -7: "EOVERFLOW16",
-          -8: "ETRACEBACK", -9: "ETOOLARGE"}
+          -8: "ETRACEBACK", -9: "ETOOLARGE", -10: "EBOUND"}
+
+# mi355sw_config.flags / .verbosity (include/mi355sw.h)
+F_FORCE_GENERIC_COMPARE, F_FORCE_INT32, F_NO_DIAGONAL_SEED, F_NO_SEED_PASS, F_NO_PRUNE_PROBE = 1, 2, 4, 8, 16
+F_TWO_PHASE, F_NO_MIXED, F_NO_SHARED_BEST, F_NO_BATCH, F_NO_HOST_COUNTER = 32, 64, 128, 256, 512
+V_MESSAGES, V_JOBS, V_SEED_TILES, V_BATCH, V_DEBUG_WORDS = 1, 2, 4, 8, 16
+
+# The C library reads no environment variable (ABI 7): the MI355SW_* switches live HERE, in the Python front, and are
+# translated into mi355sw_config fields -- when an engine is created and again before every call that starts work
+# (MI355Aligner._sync_config), so that a test or a tool may flip one between two calls on the same engine.
+_ENV_FLAGS = {"MI355SW_NO_DIAGONAL_SEED": F_NO_DIAGONAL_SEED, "MI355SW_NOSEED": F_NO_SEED_PASS, "MI355SW_NO_PRUNE_PROBE": F_NO_PRUNE_PROBE,
+              "MI355SW_TWO_PHASE": F_TWO_PHASE, "MI355SW_NO_MIXED": F_NO_MIXED, "MI355SW_NO_SHARED_BEST": F_NO_SHARED_BEST,
+              "MI355SW_NO_BATCH": F_NO_BATCH, "MI355SW_NOHOST": F_NO_HOST_COUNTER}
+_ENV_VERBOSITY = {"MI355SW_VERBOSE": V_MESSAGES, "MI355SW_VERBOSE_JOBS": V_JOBS, "MI355SW_VERBOSE_TILES": V_SEED_TILES,
+                  "MI355SW_BATCH_DEBUG": V_BATCH, "MI355SW_DEBUG": V_DEBUG_WORDS}
+
+
+def env_switches():
+    """(flags, verbosity, wait_seconds, fault_overflow_strip_plus1, stream_priority, trace_path) as the environment has them now"""
+    flags = 0
+    for name, bit in _ENV_FLAGS.items():
+        if os.environ.get(name):
+            flags |= bit
+    verbosity = 0
+    for name, bit in _ENV_VERBOSITY.items():
+        if os.environ.get(name):
+            verbosity |= bit
+    wait_s = float(os.environ.get("MI355SW_WAIT_S") or 0.0)
+    fault = os.environ.get("MI355SW_FAULT_OVERFLOW_STRIP")
+    prio = {"low": 2, "normal": 1}.get(os.environ.get("MI355SW_STREAM_PRIO", ""), 0)
+    return flags, verbosity, max(wait_s, 0.0), (int(fault) + 1) if fault not in (None, "") else 0, prio, os.environ.get("MI355SW_TRACE") or None
 
 
 class AlignerError(RuntimeError):
@@ -61,7 +91,8 @@ class Partition(C.Structure):
 class Config(C.Structure):
     _fields_ = [("device", C.c_int32), ("rows_per_lane", C.c_int32), ("waves", C.c_int32),
                 ("flags", C.c_int32), ("max_special_bytes", C.c_int64), ("block_score_columns", C.c_int32),
-                ("reserved_", C.c_int32)]
+                ("verbosity", C.c_int32), ("wait_seconds", C.c_double), ("fault_overflow_strip_plus1", C.c_int32),
+                ("stream_priority", C.c_int32), ("trace_path", C.c_char_p), ("reserved_", C.c_int64 * 4)]
 
 
 class Capabilities(C.Structure):
@@ -143,7 +174,7 @@ class ManagerTable(C.Structure):
 
 # every symbol include/mi355sw.h declares (tests check the .so exports all of them)
 ABI_SYMBOLS = [
-    "mi355sw_create", "mi355sw_destroy", "mi355sw_last_error", "mi355sw_abi_version", "mi355sw_build_id",
+    "mi355sw_create", "mi355sw_configure", "mi355sw_destroy", "mi355sw_last_error", "mi355sw_abi_version", "mi355sw_build_id",
     "mi355sw_get_capabilities", "mi355sw_get_score_parameters", "mi355sw_set_rows_per_lane",
     "mi355sw_set_sequences", "mi355sw_unset_sequences", "mi355sw_align_partition", "mi355sw_align_partitions",
     "mi355sw_process_block", "mi355sw_match_last_column", "mi355sw_progress",
@@ -195,6 +226,7 @@ def load_library():
     lib = C.CDLL(LIB_PATH)
     H = C.c_void_p
     lib.mi355sw_create.argtypes = [C.POINTER(Config), C.POINTER(H)]
+    lib.mi355sw_configure.argtypes = [H, C.POINTER(Config)]
     lib.mi355sw_destroy.argtypes = [H]
     lib.mi355sw_destroy.restype = None
     lib.mi355sw_last_error.argtypes = [H]
@@ -309,10 +341,16 @@ def _cells(a):
 class MI355Aligner:
     """Python mirror of the IAligner a MASA extension implements (M/libmasa/IAligner.hpp)."""
 
-    def __init__(self, device=-1, rows_per_lane=0, waves=0, flags=0, max_special_bytes=0, block_score_columns=0):
+    def __init__(self, device=-1, rows_per_lane=0, waves=0, flags=0, max_special_bytes=0, block_score_columns=0, verbosity=0,
+                 wait_seconds=0.0):
         self._lib = load_library()
         self._h = C.c_void_p()
-        cfg = Config(device, rows_per_lane, waves, flags, max_special_bytes, block_score_columns, 0)
+        # what the caller asked for; the environment's switches are OR-ed in by _make_config
+        self._opts = dict(device=int(device), rows_per_lane=int(rows_per_lane), waves=int(waves), flags=int(flags),
+                          max_special_bytes=int(max_special_bytes), block_score_columns=int(block_score_columns),
+                          verbosity=int(verbosity), wait_seconds=float(wait_seconds))
+        cfg = self._make_config()
+        self._cfg_key = self._config_key(cfg)
         self._rows_per_lane = int(rows_per_lane)
         rc = self._lib.mi355sw_create(C.byref(cfg), C.byref(self._h))
         if rc != 0:
@@ -322,6 +360,53 @@ class MI355Aligner:
         self._seqs = None
 
     # -- plumbing -------------------------------------------------------------------------
+    def _make_config(self):
+        o = self._opts
+        eflags, everb, ewait, efault, eprio, etrace = env_switches()
+        cfg = Config()
+        cfg.device, cfg.rows_per_lane, cfg.waves = o["device"], o["rows_per_lane"], o["waves"]
+        cfg.flags = o["flags"] | eflags
+        cfg.max_special_bytes, cfg.block_score_columns = o["max_special_bytes"], o["block_score_columns"]
+        cfg.verbosity = o["verbosity"] | everb
+        cfg.wait_seconds = o["wait_seconds"] if o["wait_seconds"] > 0 else ewait
+        cfg.fault_overflow_strip_plus1 = o.get("fault_overflow_strip_plus1", 0) or efault
+        cfg.stream_priority = eprio
+        cfg.trace_path = etrace.encode() if etrace else None
+        return cfg
+
+    @staticmethod
+    def _config_key(cfg):
+        return (cfg.rows_per_lane, cfg.waves, cfg.flags, cfg.max_special_bytes, cfg.block_score_columns, cfg.verbosity, cfg.wait_seconds,
+                cfg.fault_overflow_strip_plus1, cfg.trace_path)
+
+    def _sync_config(self):
+        """hand the library the switches as they are NOW (constructor arguments, configure(), the MI355SW_* environment)"""
+        cfg = self._make_config()
+        key = self._config_key(cfg)
+        if key != self._cfg_key:
+            self._check(self._lib.mi355sw_configure(self._h, C.byref(cfg)), "configure")
+            self._cfg_key = key
+
+    def configure(self, **kw):
+        """change switches of a live engine: flags, verbosity, wait_seconds, waves, rows_per_lane, max_special_bytes,
+        block_score_columns, fault_overflow_strip_plus1 (mi355sw_configure; no stream may be active)"""
+        for k in kw:
+            if k not in ("flags", "verbosity", "wait_seconds", "waves", "rows_per_lane", "max_special_bytes", "block_score_columns",
+                         "fault_overflow_strip_plus1"):
+                raise TypeError("configure: unknown option %r" % k)
+        self._opts.update(kw)
+        if "rows_per_lane" in kw:
+            self._rows_per_lane = int(kw["rows_per_lane"])
+        self._sync_config()
+
+    def setFlag(self, bit, on=True):
+        """one MI355SW_F_* bit on or off for the calls that follow"""
+        f = self._opts["flags"]
+        self.configure(flags=(f | bit) if on else (f & ~bit))
+
+    def getFlags(self):
+        return self._opts["flags"]
+
     def _check(self, rc, what):
         if rc != 0:
             msg = self._lib.mi355sw_last_error(self._h)
@@ -350,6 +435,8 @@ class MI355Aligner:
         """strip height (64 * rows_per_lane rows) of the partitions that follow; 0 = the engine's cost model"""
         self._check(self._lib.mi355sw_set_rows_per_lane(self._h, int(rows_per_lane)), "setRowsPerLane")
         self._rows_per_lane = int(rows_per_lane)
+        self._opts["rows_per_lane"] = int(rows_per_lane)
+        self._cfg_key = self._config_key(self._make_config())
 
     def getRowsPerLane(self):
         return getattr(self, "_rows_per_lane", None)
@@ -360,6 +447,7 @@ class MI355Aligner:
         return {"match": p.match, "mismatch": p.mismatch, "gap_open": p.gap_open, "gap_ext": p.gap_ext}
 
     def setSequences(self, seq0, seq1, seq0_len=None, seq1_len=None):
+        self._sync_config()
         s0, s1 = _as_u8(seq0), _as_u8(seq1)
         l0 = len(s0) if seq0_len is None else seq0_len
         l1 = len(s1) if seq1_len is None else seq1_len
@@ -372,6 +460,7 @@ class MI355Aligner:
 
     def alignPartition(self, partition, manager):
         """manager: object with the IManager methods (see manager.Stage1Manager)."""
+        self._sync_config()
         table, keep = make_manager_table(manager)
         self._check(self._lib.mi355sw_align_partition(self._h, C.byref(partition), C.byref(table), None),
                     "alignPartition")
@@ -386,6 +475,7 @@ class MI355Aligner:
         assert n == len(managers)
         if n == 0:
             return
+        self._sync_config()
         parts = (Partition * n)(*[Partition(p.i0, p.j0, p.i1, p.j1) for p in partitions])
         tables, keeps = zip(*[make_manager_table(m) for m in managers])
         ptrs = (C.POINTER(ManagerTable) * n)(*[C.pointer(t) for t in tables])
@@ -399,6 +489,7 @@ class MI355Aligner:
     def processBlock(self, row, col, i0, j0, i1, j1, recurrence_type):
         """AbstractBlockProcessor::processBlock: row (n,2), col (m+1,2) int32, updated in place."""
         assert row.dtype == np.int32 and col.dtype == np.int32 and row.flags.c_contiguous and col.flags.c_contiguous
+        self._sync_config()
         s = Score()
         self._check(self._lib.mi355sw_process_block(self._h, row.ctypes.data, col.ctypes.data, i0, j0, i1, j1,
                                                     recurrence_type, C.byref(s)), "processBlock")
@@ -431,6 +522,7 @@ class MI355Aligner:
         """mi355sw_seed_bound: the diagonal seed pass over `partition` -- the WHOLE matrix a chain of bands divides among itself
         -- on this engine's GPU; returns the value for streamBegin(initial_bound=...) of every band, or None when there is
         none (an unrelated pair, a small matrix)."""
+        self._sync_config()
         have, bound = C.c_int32(0), C.c_int32(0)
         self._check(self._lib.mi355sw_seed_bound(self._h, C.byref(partition), int(recurrence_type), C.byref(have), C.byref(bound)), "seedBound")
         return int(bound.value) if have.value else None
@@ -442,6 +534,7 @@ class MI355Aligner:
                     force_int32=False, prune_blocks=False, prune_rows=0, prune_cols=0,
                     first_column_port=False, last_column_port=False, first_column_resume_rows=0, share_best=False,
                     initial_bound=None):
+        self._sync_config()
         sp = StreamParams()
         sp.recurrence_type = recurrence_type
         sp.first_row_init_type, sp.first_row_start_offset = first_row_init_type, first_row_start_offset

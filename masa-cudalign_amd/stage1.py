@@ -7,7 +7,7 @@ best score as an uninterrupted one."""
 import os
 import time
 
-from .engine import Partition
+from .engine import Partition, F_NO_DIAGONAL_SEED
 from .manager import (Stage1Manager, ArrayCellsReader, InitialCellsReader, AT_ANYWHERE, AT_SEQUENCE_1, AT_SEQUENCE_2,
                       AT_SEQUENCE_1_OR_2, GAP_OPEN, GAP_EXT)
 from . import sra as sra_mod
@@ -150,14 +150,14 @@ def stage1(aligner, seq0, seq1, work, alignment_start=AT_ANYWHERE, alignment_end
     # --max-alignments > 1: the weaker alignments are candidates too, and a pruning bound that starts from the score of the
     # best one (the engine's diagonal seed pass) removes them sooner than a bound that grows with the sweep, as the
     # reference's does -- the seed is left out then (include/mi355sw.h: MI355SW_F_NO_DIAGONAL_SEED)
-    seed_off = max_alignments != 1 and "MI355SW_NO_DIAGONAL_SEED" not in os.environ
+    seed_off = max_alignments != 1 and hasattr(aligner, "setFlag") and not (aligner.getFlags() & F_NO_DIAGONAL_SEED)
     if seed_off:
-        os.environ["MI355SW_NO_DIAGONAL_SEED"] = "1"
+        aligner.setFlag(F_NO_DIAGONAL_SEED, True)
     try:
         aligner.alignPartition(rel, mgr)
     finally:
         if seed_off:
-            del os.environ["MI355SW_NO_DIAGONAL_SEED"]
+            aligner.setFlag(F_NO_DIAGONAL_SEED, False)
         stop_log()
         if part_sra is not None:
             part_sra.close()

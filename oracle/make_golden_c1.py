@@ -31,10 +31,15 @@ sys.path.insert(0, ROOT)
 import __graft_entry__ as graft  # noqa: E402
 
 
+HEAD_CELLS = 16385     # digest of the first cells of every boundary column as well (rows 0..16384): what the C restatement of the
+#                        oracle can recompute in seconds (tests/test_oracle_golden.py) -- the full columns take the GPU
+
+
 def cells_digest(a):
     a = np.ascontiguousarray(a, dtype=np.int32)
     return {"len": int(a.shape[0]), "sha256": hashlib.sha256(a.tobytes()).hexdigest(),
-            "head": a[:4].tolist(), "tail": a[-4:].tolist(), "max_h": int(a[:, 0].max())}
+            "head": a[:4].tolist(), "tail": a[-4:].tolist(), "max_h": int(a[:, 0].max()),
+            "head_cells": min(HEAD_CELLS, int(a.shape[0])), "head_sha256": hashlib.sha256(a[:HEAD_CELLS].tobytes()).hexdigest()}
 
 
 def copier(src, dst, keep):

@@ -21,6 +21,10 @@ class OracleStreamEngine:
     def __init__(self, oracle, seq0, seq1, seg=256):
         self.o, self.s0, self.s1, self.seg = oracle, seq0, seq1, seg
         self.in_shm = self.out_shm = None
+        self._opts = {"wait_seconds": 0.0}          # MI355Aligner.configure's switches (mi355sw_config)
+
+    def configure(self, **kw):
+        self._opts.update(kw)
 
     # -- column ports, stood in by POSIX shared memory between the rank processes: int32 row counter at +0, cells from
     #    +256 -- the layout of the engine's port (csrc/runtime.cpp); the "kernel" below publishes and polls like
@@ -122,7 +126,7 @@ class OracleStreamEngine:
                     import time
                     from masa_cudalign_amd.engine import AlignerError
                     self.t_wait = self.t_wait or time.time()
-                    if time.time() - self.t_wait > float(os.environ.get("MI355SW_WAIT_S", "3600")):
+                    if time.time() - self.t_wait > (self._opts["wait_seconds"] or 3600.0):    # mi355sw_config.wait_seconds
                         raise AlignerError("stream_poll: wait budget exhausted on the inbound column")
                 else:
                     self.t_wait = None
@@ -381,7 +385,9 @@ def _worker_verify(rank, world, port, m, n, fault, q):
             return int(t.item())
         ok = all_min(1 if runner.probe_p2p(m) else 0) == 1
         verified = ok and runner.verify_p2p(m // 3, lim[rank], lim[rank + 1], all_min, budget_s=3.0)
-        env_restored = "MI355SW_WAIT_S" not in os.environ and "MI355SW_BAND_STALL_S" not in os.environ
+        # the check's time budget travels as configuration (engine.configure, runner.stall_abort_s), not through os.environ
+        env_restored = ("MI355SW_WAIT_S" not in os.environ and "MI355SW_BAND_STALL_S" not in os.environ and
+                        eng._opts["wait_seconds"] == 0.0 and runner.stall_abort_s is None)
         if not verified:
             runner.transport = "host"
             eng.portClose()
