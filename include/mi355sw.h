@@ -103,6 +103,8 @@ typedef struct {
 #define MI355SW_F_NO_MIXED 64               /* never two strip heights in one launch */
 #define MI355SW_F_NO_SHARED_BEST 128        /* share_best streams keep their running best to themselves */
 #define MI355SW_F_NO_BATCH 256              /* mi355sw_align_partitions runs its partitions one by one */
+#define MI355SW_F_NO_WINDOW 1024            /* pruning runs without the pruning window: every strip walks the whole width and writes every
+                                               skipped cell (A/B measurements, tests) */
 #define MI355SW_F_NO_HOST_COUNTER 512       /* the kernel does not mirror its strip counter into host memory (measurements) */
 #define MI355SW_V_MESSAGES 1                /* one line per noteworthy event (overflow reruns, the diagonal seed, ...) */
 #define MI355SW_V_JOBS 2                    /* timing of every mi355sw_align_partition job */

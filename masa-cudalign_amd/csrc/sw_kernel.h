@@ -78,6 +78,8 @@ struct KernelArgs {
     int mix_first;               // strips [0, mix_first) have the kernel's first height, the rest its second (mixed-height
                                  // launches, sw_strip_kernel_pk16_mixed); INT_MAX for the ordinary kernels
     int strip_row0_b;            // DP row of strip s >= mix_first = strip_row0_b + s * (second height)
+    int* win;                    // pruning kernels: the strips' windows, 2 ints per strip + 2 for the row above -- [gap_lo, gap_hi) of output
+                                 // columns strip s left unwritten at win[2(s+1)] (see WIN_RETIRED in sw_kernel_pk16.inc) -- or nullptr (no window)
     const int* gbest_in;         // where the strips READ the running best from: gbest itself, or a word that stays at -INF
                                  // when every strip record must be that strip's own exact best (block scores) instead
                                  // of "nothing below what is already known elsewhere"
@@ -262,6 +264,7 @@ int stage4_refine(const unsigned char* d_seq0, long long len0, const unsigned ch
                   hipStream_t stream, std::vector<Stage4Crosspoint>& list, int max_size, Stage4Stats* stats, hipError_t* hip_err);
 hipError_t launch_fill_bus(int2* bus, int n, int init_type, int start_offset, hipStream_t stream);
 hipError_t launch_fill_int(int* p, long long count, int value, hipStream_t stream);
+hipError_t launch_fill_cells(int2* p, long long count, int h, int f, hipStream_t stream);
 
 }  // namespace mi355sw
 #endif

@@ -407,6 +407,11 @@ __global__ void fill_int_kernel(int* p, long long count, int value) {
     for (long long k = (long long) blockIdx.x * blockDim.x + threadIdx.x; k < count; k += stride) p[k] = value;
 }
 
+__global__ void fill_cells_kernel(int2* p, long long count, int2 value) {
+    const long long stride = (long long) gridDim.x * blockDim.x;
+    for (long long k = (long long) blockIdx.x * blockDim.x + threadIdx.x; k < count; k += stride) p[k] = value;
+}
+
 template <int R>
 static hipError_t launch_r(const KernelArgs* a, int grid, hipStream_t stream, bool sw, bool profile, bool track) {
 #define LAUNCH(SWV, PRV, TRV) \
@@ -450,6 +455,13 @@ hipError_t launch_fill_int(int* p, long long count, int value, hipStream_t strea
     long long b = (count + 255) / 256;
     int blocks = (int) (b > 2048 ? 2048 : (b < 1 ? 1 : b));
     hipLaunchKernelGGL(fill_int_kernel, dim3(blocks), dim3(256), 0, stream, p, count, value);
+    return hipGetLastError();
+}
+
+hipError_t launch_fill_cells(int2* p, long long count, int h, int f, hipStream_t stream) {
+    long long b = (count + 255) / 256;
+    int blocks = (int) (b > 8192 ? 8192 : (b < 1 ? 1 : b));
+    hipLaunchKernelGGL(fill_cells_kernel, dim3(blocks), dim3(256), 0, stream, p, count, make_int2(h, f));
     return hipGetLastError();
 }
 

@@ -335,7 +335,9 @@ void oracle_free_result(oc_result* r) {
 /* ------------------------------------------------------------------------- *
  * Multi-threaded anti-diagonal wavefront of blocks (no pruning).  Same cells,
  * same per-block best, same canonical reduction => same result as the serial
- * schedule.  Used only as the "port" CPU baseline in bench.py.
+ * schedule.  The "port" CPU baseline in bench.py; the tests use it where the
+ * serial schedule would take minutes (special rows, last row and last column are
+ * the same cells whatever the block schedule).
  * ------------------------------------------------------------------------- */
 typedef struct {
     const oc_params* p;
@@ -347,6 +349,8 @@ typedef struct {
     volatile int next;     /* next block index on the diagonal */
     pthread_barrier_t bar;
     int threads;
+    int interval_blocks;   /* special rows: every interval_blocks-th block row (0 = none) */
+    oc_result* r;
 } mt_ctx;
 
 static void* mt_worker(void* arg) {
@@ -361,8 +365,26 @@ static void* mt_worker(void* arg) {
             if (by >= c->gh || bx < 0) break;
             int i0 = by * c->bh, i1 = (i0 + c->bh > p->m) ? p->m : i0 + c->bh;
             int j0 = bx * c->bw, j1 = (j0 + c->bw > p->n) ? p->n : j0 + c->bw;
-            c->scores[(size_t) bx * c->gh + by] = oracle_process_block(p->seq0, p->seq1,
-                    c->rowbuf + j0, c->colbufs + (size_t) by * (c->bh + 1), i0, j0, i1, j1, p->recurrence);
+            oc_cell* row = c->rowbuf + j0;
+            oc_cell* col = c->colbufs + (size_t) by * (c->bh + 1);
+            const int special = (c->interval_blocks && (by + 1) % c->interval_blocks == 0);
+            const int lastrow = (c->r->last_row != NULL && by == c->gh - 1);
+            oc_cell* srow = special ? c->r->special_rows + (size_t) ((by + 1) / c->interval_blocks - 1) * (p->n + 1) : NULL;
+            if (bx == 0 && (special || lastrow)) {          /* the row's first cell: the first column's, F void (as the serial schedule) */
+                oc_cell f = col[i1 - i0];
+                f.f = -OC_INF;
+                if (special) srow[0] = f;
+                if (lastrow) c->r->last_row[0] = f;
+            }
+            if (by == 0 && bx == c->gw - 1 && c->r->last_col != NULL) {
+                oc_cell f = row[j1 - j0 - 1];
+                f.f = -OC_INF;
+                c->r->last_col[0] = f;
+            }
+            c->scores[(size_t) bx * c->gh + by] = oracle_process_block(p->seq0, p->seq1, row, col, i0, j0, i1, j1, p->recurrence);
+            if (special) memcpy(srow + 1 + j0, row, sizeof(oc_cell) * (size_t) (j1 - j0));
+            if (lastrow) memcpy(c->r->last_row + 1 + j0, row, sizeof(oc_cell) * (size_t) (j1 - j0));
+            if (bx == c->gw - 1 && c->r->last_col != NULL) memcpy(c->r->last_col + 1 + i0, col + 1, sizeof(oc_cell) * (size_t) (i1 - i0));
         }
         pthread_barrier_wait(&c->bar);
         if (__sync_bool_compare_and_swap(&c->diag, d, d + 1)) c->next = 0;
@@ -386,6 +408,23 @@ int oracle_stage1_mt(const oc_params* p, oc_result* r, int threads) {
     c.colbufs = (oc_cell*) malloc(sizeof(oc_cell) * (size_t) c.gh * (c.bh + 1));
     c.scores = (oc_score*) malloc(sizeof(oc_score) * (size_t) c.gw * c.gh);
     c.threads = threads;
+    c.r = r;
+    if (p->special_row_interval > 0) {                      /* AbstractBlockAligner.cpp:418-439, as oracle_stage1 */
+        c.interval_blocks = (p->special_row_interval + c.bh - 1) / c.bh;
+        if (c.interval_blocks <= 0) c.interval_blocks = 1;
+        const int rows = c.gh / c.interval_blocks;
+        if (rows > 0) {
+            r->special_rows = (oc_cell*) malloc(sizeof(oc_cell) * (size_t) rows * (p->n + 1));
+            r->special_row_ids = (int*) malloc(sizeof(int) * (size_t) rows);
+            for (int k = 0; k < rows; k++) {
+                const int i1 = (k + 1) * c.interval_blocks * c.bh;
+                r->special_row_ids[k] = i1 > p->m ? p->m : i1;
+            }
+            r->n_special_rows = rows;
+        }
+    }
+    if (p->want_last_row) r->last_row = (oc_cell*) malloc(sizeof(oc_cell) * (size_t) (p->n + 1));
+    if (p->want_last_col) r->last_col = (oc_cell*) malloc(sizeof(oc_cell) * (size_t) (p->m + 1));
     /* borders: corner + first row, and the whole first column split per block row */
     border_t frow, fcol;
     memset(&frow, 0, sizeof(frow)); memset(&fcol, 0, sizeof(fcol));

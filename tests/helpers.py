@@ -89,3 +89,13 @@ def oracle_kwargs(oracle, p, m, n):
     if kw["special_row_interval"]:
         kw["want_last_row"] = True     # SpecialRowsPartition always hands out a last-row writer
     return kw
+
+
+def oracle_full(oracle, seq0, seq1, edge=0, special_row_interval=8192):
+    """the oracle's whole-matrix answer for the larger GPU parity cases -- best cell, last row, last column, special rows every
+    `special_row_interval` rows -- on every host core (oracle_stage1_mt: the same cells as the serial schedule, pinned on it by
+    tests/test_oracle_golden.py::test_threaded_oracle_equals_the_serial_one).  edge: 0 = local (**), 4 = global (++)."""
+    m, n = len(seq0), len(seq1)
+    kw = oracle_kwargs(oracle, dict(start=edge, end=edge, pruning=False, disk=-1, block=(1024, 1024)), m, n)
+    kw.update(want_last_row=True, want_last_col=True, special_row_interval=special_row_interval, threads=min(64, os.cpu_count() or 1))
+    return oracle.stage1(seq0, seq1, **kw)

@@ -75,3 +75,42 @@ def test_stage4_restatement_reproduces_the_reference_file(case, pkg, oracle):
     txt = "START\n" + "".join("%d,%d,%d,%d\n" % p for p in pts) + "END\n"
     assert len(pts) == case["crosspoints_4"]["count"]
     assert hashlib.sha256(txt.encode()).hexdigest() == case["crosspoints_4"]["file_sha256"]
+
+
+def test_c1_reference_fixture_pins_the_restatement(pkg, oracle):
+    """BASELINE config C1 (1 000 000 x 1 000 000 unrelated, local SW) went once through MASA-Core's own CPU path as a chain of
+    eight column bands (oracle/make_golden_c1.py -> tests/golden/c1_reference.json: best cell, the seven boundary columns,
+    ten special rows).  The whole matrix is the GPU's to reproduce (tests/test_gpu_c1.py); here the C restatement recomputes
+    what it can in seconds -- the first 16 384 rows of band 1 -- and must give the head of the reference's first boundary column."""
+    import hashlib
+    import json
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "c1_reference.json")
+    with open(path) as f:
+        fx = json.load(f)
+    assert fx["m"] == fx["n"] == 1000000 and fx["parts"] == 8 and len(fx["boundary_columns"]) == 7 and len(fx["special_rows"]) >= 8
+    s0, s1 = pkg.seqgen.unrelated_pair(fx["m"], fx["n"], cfg=fx["seq"]["cfg"])
+    assert hashlib.sha256(s0.tobytes()).hexdigest() == fx["seq0_sha256"] and hashlib.sha256(s1.tobytes()).hexdigest() == fx["seq1_sha256"]
+    assert fx["best"] == fx["band_bests"][-1] and fx["best"][2] == max(b[2] for b in fx["band_bests"])
+    j = fx["band_limits"][1]
+    col = fx["boundary_columns"][str(j)]
+    rows = col["head_cells"] - 1
+    ref = oracle.stage1(s0[:rows], s1[:j], want_last_col=True)
+    got = np.ascontiguousarray(ref["last_col"], dtype=np.int32)
+    assert got.shape == (rows + 1, 2) and got[:4].tolist() == col["head"]
+    assert hashlib.sha256(got.tobytes()).hexdigest() == col["head_sha256"]
+
+
+@pytest.mark.parametrize("m,n,edge", [(30000, 26000, 0), (20000, 31000, 4), (8191, 5000, 0), (16384, 3000, 0)])
+def test_threaded_oracle_equals_the_serial_one(pkg, oracle, m, n, edge):
+    """oracle_stage1_mt (blocks on an anti-diagonal wavefront of threads) hands out the serial schedule's best cell, special
+    rows, last row and last column: the larger GPU parity cases use it (helpers.oracle_full)"""
+    s0, s1 = pkg.seqgen.related_pair(m, n, cfg=3)
+    kw = oracle_kwargs(oracle, dict(start=edge, end=edge, pruning=False, disk=-1, block=(1024, n)), m, n)
+    kw.update(want_last_row=True, want_last_col=True, special_row_interval=8192)
+    a = oracle.stage1(s0, s1, **kw)
+    kw.update(block_w=1000, threads=8)
+    b = oracle.stage1(s0, s1, **kw)
+    assert a["best"] == b["best"] and a["special_row_ids"] == b["special_row_ids"] and len(a["special_row_ids"]) >= 1
+    assert np.array_equal(a["last_row"], b["last_row"]) and np.array_equal(a["last_col"], b["last_col"])
+    assert np.array_equal(a["special_rows"], b["special_rows"])

@@ -1,0 +1,81 @@
+#!/bin/bash
+# tools/gpu_call.sh TAG STEP [STEP...]  -- ONE script for the GPU calls of a round (run ON THE GPU BOX through gpurun, from the
+# repo root); replaces the per-round one-offs (r03_*.sh, r04_*.sh).  Everything lands under gpurun_out/TAG/.
+#   new:FILES      pytest -m gpu -x of the listed test files (comma separated, without tests/ and .py)
+#   suite          the whole GPU suite (pytest tests -m gpu), then __graft_entry__.smoke()
+#   bench          python3 bench.py (the driver's N = 1 command) -> bench.json
+#   selflaunch:N   MI355SW_BENCH_REHEARSAL=1 python3 bench.py --gpus N --size 300000  (bench.py starts its own ranks; all on cuda:0)
+#   rehearse       the N > 1 path of bench.py on the one GPU through every transport and recurrence (self-launched)
+#   ab:M,N[,R]     a related M x N pair: unpruned, pruned with the window, pruned without it (tools/window_probe.py)
+#   c3             C3's stage 1 at full size (tools/scale_run.py c3) -> scale_c3.json
+#   pmc            rocprofv3 kernel statistics + PMC passes of the default bench command (tools/pmc_collect.sh TAG)
+#   py:SCRIPT,ARGS python3 tools/SCRIPT ARGS... (comma separated)
+tag=$1; shift
+out=gpurun_out/$tag
+mkdir -p $out
+export TMPDIR=/tmp
+for step in "$@"; do
+    name=${step%%:*}; arg=""; [ "$step" != "$name" ] && arg=${step#*:}
+    t0=$(date +%s)
+    case $name in
+    new)
+        files=$(echo $arg | tr ',' '\n' | sed 's#^#tests/#; s#$#.py#' | tr '\n' ' ')
+        timeout 1500 python3 -m pytest $files -x -q -m gpu -s > $out/new_tests.log 2>&1; rc=$?
+        tail -15 $out/new_tests.log ;;
+    suite)
+        timeout 2400 python3 -m pytest tests -q -m gpu > $out/suite.log 2>&1; rc=$?
+        tail -8 $out/suite.log
+        timeout 300 python3 -c "import __graft_entry__ as g; g.smoke()" > $out/smoke.log 2>&1; echo "smoke rc=$?"; tail -2 $out/smoke.log ;;
+    bench)
+        timeout 1700 python3 bench.py > $out/bench.json 2> $out/bench.err; rc=$?
+        python3 - <<PY
+import json
+try:
+    d = json.loads(open("$out/bench.json").read().strip().splitlines()[-1])
+    print("bench value %.1f GCUPS, ms/step %.2f, roofline %.5f, kernel %s" % (d["value"], d["ms_per_step"], d["roofline"]["frac"], d["config"]["kernel_name"]))
+    for k in ("target_shape", "c3_shape", "c5_shape", "c3_full", "cpu_baseline"):
+        if k in d:
+            v = d[k]
+            print(" ", k, {kk: (round(vv, 2) if isinstance(vv, float) else vv) for kk, vv in v.items() if not isinstance(vv, (dict, list))}, v.get("check"))
+except Exception as e:
+    print("bench line unreadable:", e)
+PY
+        ;;
+    selflaunch)
+        MI355SW_BENCH_REHEARSAL=1 MI355SW_BENCH_TIMEOUT_S=600 python3 bench.py --gpus $arg --steps 2 --warmup 1 --size 300000 > $out/selflaunch_$arg.json 2> $out/selflaunch_$arg.err; rc=$?
+        python3 -c "
+import json
+d=json.loads(open('$out/selflaunch_$arg.json').read().strip().splitlines()[-1]); c=d['config']
+print('self-launched N=%d: value %.0f comm %s launcher %s xgmi %s note %s best %s' % (d['n_gpus'], d['value'], c['comm'], c['launcher'], c['xgmi'], c['comm_note'], d['best']))" ;;
+    rehearse)
+        rc=0
+        run() { n=$1; t=$2; shift 2
+            MI355SW_BENCH_REHEARSAL=1 MI355SW_BENCH_TIMEOUT_S=600 python3 bench.py --gpus $n --steps 2 --warmup 1 --size 300000 "$@" > $out/rehearsal_$t.json 2> $out/rehearsal_$t.err
+            r=$?; [ $r -ne 0 ] && rc=$r
+            python3 -c "
+import json
+d=json.loads(open('$out/rehearsal_$t.json').read().strip().splitlines()[-1]); c=d['config']
+print('rehearsal $t rc=$r: value %.0f comm %s launcher %s pruned %.3f best %s kernel %s' % (d['value'], c['comm'], c['launcher'], c['pruned_fraction'], d['best'], c['kernel_name']))" || echo "rehearsal $t rc=$r: no line"; }
+        run 2 n2
+        run 4 n4_related --related
+        run 4 n4_nw_related --nw --related
+        run 8 n8_nw_related --nw --related
+        MI355SW_BENCH_COMM=host run 4 n4_related_host --related
+        MI355SW_BENCH_FAIL_IPC=1 run 4 n4_attach --related
+        MI355SW_BENCH_FAIL_IPC=1 MI355SW_BENCH_NO_ATTACH=1 run 4 n4_host_after_both_failed --related ;;
+    ab)
+        timeout 1500 python3 tools/window_probe.py $(echo $arg | tr ',' ' ') > $out/ab_$(echo $arg | tr ',' 'x').log 2>&1; rc=$?
+        cat $out/ab_$(echo $arg | tr ',' 'x').log ;;
+    c3)
+        timeout 1500 python3 tools/scale_run.py c3 $out/scale_c3.json > $out/scale_c3.log 2>&1; rc=$?
+        tail -5 $out/scale_c3.log ;;
+    pmc)
+        bash tools/pmc_collect.sh $tag > $out/pmc.log 2>&1; rc=$? ;;
+    py)
+        script=${arg%%,*}; rest=""; [ "$arg" != "$script" ] && rest=$(echo ${arg#*,} | tr ',' ' ')
+        timeout 1700 python3 tools/$script $rest > $out/${script%.py}.log 2>&1; rc=$?
+        tail -20 $out/${script%.py}.log ;;
+    *) echo "unknown step $step"; rc=2 ;;
+    esac
+    echo "== step $step rc=$rc $(( $(date +%s) - t0 )) s"
+done
