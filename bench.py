@@ -235,6 +235,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-shapes", action="store_true", help="N = 1: skip the C3- and C5-shaped checks (c3_shape, c5_shape)")
     ap.add_argument("--no-target-shape", action="store_true", help="N = 1: skip the 228 M-row north-star-height step")
+    ap.add_argument("--no-c3-full", action="store_true", help="N = 1: skip BASELINE config 3's stage 1 at full size (c3_full, about two minutes)")
     ap.add_argument("--no-single-reference", action="store_true",
                     help="N > 1: skip rank 0's untimed run of ONE GPU's share of the cells (tall*size x size) alone")
     ap.add_argument("--launch-check", action="store_true",
@@ -555,6 +556,11 @@ def main():
                     out[key] = fn(pkg, local_rank)
                 except Exception as e:                   # noqa: BLE001
                     out[key] = {"error": "%s: %s" % (type(e).__name__, e)}
+        if world == 1 and not args.no_c3_full:
+            try:
+                out["c3_full"] = c3_full(pkg, local_rank)
+            except Exception as e:                       # noqa: BLE001
+                out["c3_full"] = {"error": "%s: %s" % (type(e).__name__, e)}
         if world == 1 and not args.no_cpu_baseline:
             for key, fn in (("cpu_baseline", cpu_baseline), ("cpu_baseline_all_cores", cpu_baseline_mt)):
                 try:
@@ -665,6 +671,65 @@ def c3_shape(pkg, device):
     out["check"] = {"same_best_cell": tuple(b0) == tuple(b1) == tuple(b2), "same_rows": sorted(r0) == sorted(r1) == sorted(r2) and len(r0) >= 4,
                     "pruned_rows_are_lower_bounds": lower, "row_maxima_above_the_best_cell_intact": maxima}
     out["check"]["ok"] = all(out["check"].values())
+    return out
+
+
+# C3's stage 1 without pruning, swept once on this engine family (builder-side, 6 minutes of GPU: tools/scale_run.py c3 ->
+# profiles/r04_scale_c3_48Mx46M.json "unpruned"): the best cell a pruned run of the same pair must report (0-based i, j)
+C3_RECORDED_UNPRUNED_BEST = (45999788, 45999999, 35906671)
+
+
+def c3_full(pkg, device):
+    """BASELINE config 3's stage 1 AT FULL SIZE under the driver's clock: 48 M x 46 M related pair, local SW, block pruning on
+    (the bound starts from the diagonal seed pass), special rows every 2 Mi rows.  GCUPS in the reference's m*n convention
+    (sw_stage1.cpp:440-448) over the whole call, seed included.  Checks that do not take the run's own word: the first 3 M
+    columns of the same matrix swept WITHOUT pruning (a band with a zero first column is a matrix in its own right: exact
+    cells) -- every special row of the pruned run is a lower bound of it there, and where the alignment crosses a row inside
+    the band the row's maximum is the same, at the same column; the rows' maxima rise strictly down to the best cell; the
+    best cell is the one the unpruned sweep of the whole matrix reported (recorded)."""
+    import numpy as np
+    from masa_cudalign_amd.bands import BandRunner
+    m, n, band = 48000000, 46000000, 3000000
+    interval = 2 << 20
+    t0 = time.time()
+    s0, s1 = pkg.seqgen.related_pair(m, n, cfg=3)
+    out = {"workload": "C3 stage 1 at full size: %dx%d related synthetic pair, local SW, block pruning on behind the diagonal seed, "
+                       "special rows every %d rows" % (m, n, interval), "generate_s": time.time() - t0}
+    al = pkg.MI355Aligner(device=device, max_special_bytes=64 << 30)
+    try:
+        al.setSequences(s0, s1)
+        kept, maxima = {}, {}
+
+        def sink(dp, c0, cells):
+            kept[dp] = cells[:band].copy()
+            h = cells[:, 0]
+            maxima[dp] = (int(h.max()), int(h.argmax()))
+        t0 = time.time()
+        br = BandRunner(al, prune_blocks=True)
+        best = br.run(m, 0, n, special_row_interval=interval, special_row_sink=sink)
+        dt = time.time() - t0
+        st = al.getStatistics()
+        out.update({"value": float(m) * n / dt / 1e9, "unit": "GCUPS (m*n, seed included)", "seconds": dt, "kernel_ms": st["kernel_ms"],
+                    "seed_ms": st["seed_ms"], "kernel": st["kernel"], "strip_rows": st["strip_rows"], "restarts": br.restarts,
+                    "pruned_fraction": st["pruned_cells"] / float(m) / n, "computed_cells_gcups": st["processed_cells"] / st["kernel_ms"] / 1e6,
+                    "special_rows": len(kept), "best": {"i": best[0] + 1, "j": best[1] + 1, "score": best[2]}})
+        # the same rows of the first `band` columns, every cell computed
+        exact = {}
+        t0 = time.time()
+        BandRunner(al).run(m, 0, band, special_row_interval=interval, special_row_sink=lambda dp, c0, cells: exact.__setitem__(dp, cells.copy()))
+        out["unpruned_band"] = {"columns": band, "seconds": time.time() - t0, "kernel": al.getStatistics()["kernel"]}
+    finally:
+        al.close()
+    lower = sorted(kept) == sorted(exact) and all(bool(np.all(kept[dp] <= exact[dp])) for dp in kept)
+    crossed = [dp for dp in sorted(exact) if int(exact[dp][:, 0].argmax()) < band - 4096 and int(exact[dp][:, 0].max()) > 1000]
+    same_max = all(int(kept[dp][:, 0].max()) == int(exact[dp][:, 0].max()) and int(kept[dp][:, 0].argmax()) == int(exact[dp][:, 0].argmax()) for dp in crossed)
+    above = [maxima[dp][0] for dp in sorted(maxima) if dp <= best[0]]
+    out["check"] = {"pruned_rows_are_lower_bounds_of_the_unpruned_band": bool(lower), "rows_crossed_inside_the_band": len(crossed),
+                    "row_maxima_equal_where_the_alignment_crosses_the_band": bool(same_max and len(crossed) >= 1),
+                    "row_maxima_rise_down_to_the_best_cell": bool(len(above) >= 10 and all(a < b for a, b in zip(above, above[1:])) and above[-1] <= best[2]),
+                    "best_cell_is_the_recorded_unpruned_sweeps": tuple(best) == C3_RECORDED_UNPRUNED_BEST,
+                    "no_restart": br.restarts == 0}
+    out["check"]["ok"] = all(v for v in out["check"].values() if isinstance(v, bool))
     return out
 
 

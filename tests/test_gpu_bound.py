@@ -35,7 +35,7 @@ def _stream(pkg, al, m, n, recurrence, bound, interval=8192, prune=True):
         k += 1
     best, nsp = al.streamEnd()
     assert nsp == k
-    out["best"] = tuple(best)
+    out["best"] = (best[0] + 1, best[1] + 1, best[2]) if best[1] >= 0 else tuple(best)      # 1-based like the oracle's (the stream's cell is 0-based)
     out["stats"] = al.getStatistics()
     return out
 

@@ -74,13 +74,16 @@ def test_window_against_the_oracle_and_against_the_run_without_it(pkg, oracle, k
             assert got["best"] == tuple(ref["best"]), (flags, got["best"], ref["best"])
         assert st["pruned_cells"] > 0 and st["pruned_cells"] + st["processed_cells"] == m * n
         assert np.all(got["last_row"] <= ref["last_row"][1:]) and np.all(got["last_col"] <= ref["last_col"][1:])
-        assert sorted(got["rows"]) == sorted(want_rows)
+        assert sorted(got["rows"]) == [i for i in sorted(want_rows) if i % 8192 == 0 and i < m] and len(got["rows"]) >= 2
         for i, cells in got["rows"].items():
             assert np.all(cells <= want_rows[i][1:]), (flags, i)
             if kind != 2:
                 assert np.all(cells[:, 0] >= 0), (flags, i)                     # a skipped cell of a local alignment reads 0, never less
-                if i <= ref["best"][0]:
-                    assert int(cells[:, 0].max()) == int(want_rows[i][1:, 0].max()), (flags, i)
+                # a row the optimal alignment crosses (its maximum is far above the noise of unrelated cells, and it lies
+                # above the best cell) carries that maximum exactly, at the same column
+                w = want_rows[i][1:, 0]
+                if i <= ref["best"][0] and int(w.max()) > 200:
+                    assert int(cells[:, 0].max()) == int(w.max()) and int(cells[:, 0].argmax()) == int(w.argmax()), (flags, i)
     a, b = res[0], res[F_NO_WINDOW]
     # the window changes what is WRITTEN, not what is skipped (up to the timing of the running bound, which may differ by a few slabs)
     assert abs(a["stats"]["pruned_cells"] - b["stats"]["pruned_cells"]) <= 0.05 * m * n, (a["stats"]["pruned_cells"], b["stats"]["pruned_cells"])
@@ -111,8 +114,11 @@ def test_strips_below_the_end_of_the_alignment_retire(pkg, oracle):
         deep = [i for i in got["rows"] if i > 200000]
         assert len(deep) >= 5
         for i in deep:
-            assert not got["rows"][i][:, 0].any() and np.all(got["rows"][i][:, 1] == -INF), (flags, i)
-        assert not got["last_row"][:, 0].any()
+            # (the strip's first two chunks are always computed: a few cells next to the first column hold what two unrelated
+            #  sequences score there; everything else was never touched and reads as the constant the host filled in)
+            row = got["rows"][i]
+            assert int(row[:, 0].max()) <= 30 and not row[256:, 0].any() and np.all(row[256:, 1] == -INF), (flags, i)
+        assert int(got["last_row"][:, 0].max()) <= 30 and not got["last_row"][256:, 0].any()
         assert got["stats"]["pruned_cells"] > 0.8 * m * n
     print("kernel ms with / without the window: %.1f / %.1f (two-phase: %.1f / %.1f)" % (
         out[0]["stats"]["kernel_ms"], out[F_NO_WINDOW]["stats"]["kernel_ms"], out[F_TWO_PHASE]["stats"]["kernel_ms"],
@@ -138,8 +144,13 @@ def test_window_through_the_manager_interface_with_pruning_on(pkg, oracle):
         st = al.getStatistics()
         assert tuple(mg.getBestScore()) == tuple(ref["best"]) and st["pruned_cells"] > 0.15 * m * n
         assert np.all(mg.lastRow() <= ref["last_row"]) and np.all(mg.lastColumn() <= ref["last_col"])
+        crossed = 0
         for i in sorted(mg.special_rows):
             got, want = mg.specialRow(i), want_rows[i]
-            assert np.all(got <= want) and got[:, 0].max() == want[:, 0].max(), i
+            assert np.all(got <= want), i
+            if i <= ref["best"][0]:                 # rows the optimal alignment crosses: its score, exactly, where the oracle has it
+                assert got[:, 0].max() == want[:, 0].max() and got[:, 0].argmax() == want[:, 0].argmax(), i
+                crossed += 1
+        assert crossed >= 5
     finally:
         al.close()

@@ -7,7 +7,7 @@
 #   selflaunch:N   MI355SW_BENCH_REHEARSAL=1 python3 bench.py --gpus N --size 300000  (bench.py starts its own ranks; all on cuda:0)
 #   rehearse       the N > 1 path of bench.py on the one GPU through every transport and recurrence (self-launched)
 #   ab:M,N[,R]     a related M x N pair: unpruned, pruned with the window, pruned without it (tools/window_probe.py)
-#   c3             C3's stage 1 at full size (tools/scale_run.py c3) -> scale_c3.json
+#   c3             C3's stage 1 at full size, pruned, against the recorded unpruned run (tools/scale_run.py c3pruned) -> scale_c3pruned.json
 #   pmc            rocprofv3 kernel statistics + PMC passes of the default bench command (tools/pmc_collect.sh TAG)
 #   py:SCRIPT,ARGS python3 tools/SCRIPT ARGS... (comma separated)
 tag=$1; shift
@@ -67,7 +67,7 @@ print('rehearsal $t rc=$r: value %.0f comm %s launcher %s pruned %.3f best %s ke
         timeout 1500 python3 tools/window_probe.py $(echo $arg | tr ',' ' ') > $out/ab_$(echo $arg | tr ',' 'x').log 2>&1; rc=$?
         cat $out/ab_$(echo $arg | tr ',' 'x').log ;;
     c3)
-        timeout 1500 python3 tools/scale_run.py c3 $out/scale_c3.json > $out/scale_c3.log 2>&1; rc=$?
+        timeout 1500 python3 tools/scale_run.py c3pruned $out/scale_c3pruned.json > $out/scale_c3.log 2>&1; rc=$?
         tail -5 $out/scale_c3.log ;;
     pmc)
         bash tools/pmc_collect.sh $tag > $out/pmc.log 2>&1; rc=$? ;;
