@@ -105,6 +105,8 @@ typedef struct {
 #define MI355SW_F_NO_BATCH 256              /* mi355sw_align_partitions runs its partitions one by one */
 #define MI355SW_F_NO_WINDOW 1024            /* pruning runs without the pruning window: every strip walks the whole width and writes every
                                                skipped cell (A/B measurements, tests) */
+#define MI355SW_F_STAIRCASE_SEED 2048       /* the diagonal seed as ONE chain of tiles down the diagonal (the round-4 form) instead of
+                                               segments between anchors swept side by side (A/B measurements, tests) */
 #define MI355SW_F_NO_HOST_COUNTER 512       /* the kernel does not mirror its strip counter into host memory (measurements) */
 #define MI355SW_V_MESSAGES 1                /* one line per noteworthy event (overflow reruns, the diagonal seed, ...) */
 #define MI355SW_V_JOBS 2                    /* timing of every mi355sw_align_partition job */

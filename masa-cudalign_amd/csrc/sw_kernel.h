@@ -80,6 +80,8 @@ struct KernelArgs {
     int strip_row0_b;            // DP row of strip s >= mix_first = strip_row0_b + s * (second height)
     int* win;                    // pruning kernels: the strips' windows, 2 ints per strip + 2 for the row above -- [gap_lo, gap_hi) of output
                                  // columns strip s left unwritten at win[2(s+1)] (see WIN_RETIRED in sw_kernel_pk16.inc) -- or nullptr (no window)
+    int band_c0, band_slope_q16, band_w;   // band mode (pruning kernels with a window; band_w > 0): only columns within band_w of
+                                 // the line  column = band_c0 + row * band_slope_q16 / 65536  (row relative to the partition) are computed
     const int* gbest_in;         // where the strips READ the running best from: gbest itself, or a word that stays at -INF
                                  // when every strip record must be that strip's own exact best (block scores) instead
                                  // of "nothing below what is already known elsewhere"
@@ -250,6 +252,7 @@ struct BatchArgs {
 hipError_t launch_strip_kernel_pk16_mixed(const KernelArgs& a, KernelArgs* dargs, int rows_per_half_a, int rows_per_half_b, int grid,
                                           hipStream_t stream, bool track, bool sw);
 hipError_t launch_batch_kernel_pk16(const BatchArgs* dbatch, int rows_per_half, int grid, hipStream_t stream, bool track, bool sw);
+hipError_t launch_batch_kernel_pk16_band(const BatchArgs* dbatch, int grid, hipStream_t stream);   // 512-row strips, NW, value-only, pruning kernels (band mode)
 
 // `dargs` = device copy of the argument block (the launcher uploads `a` into it on `stream`)
 hipError_t launch_strip_kernel(const KernelArgs& a, KernelArgs* dargs, int rows_per_lane, int grid, hipStream_t stream,
