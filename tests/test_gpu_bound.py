@@ -214,3 +214,37 @@ def test_late_homology_at_four_million_columns(pkg):
         assert res[True][1]["pruned_cells"] > 0.3 * m * n, res[True][1]
     finally:
         al.close()
+
+
+def test_a_co_optimal_path_that_can_only_tie_survives_pruning(pkg, oracle):
+    """Three exact copies of one 22 000-mer in seq0 against one in seq1, cut so that the SECOND copy's alignment ends exactly in the
+    matrix's last cell: it can only ever TIE the score the first copy reached 24 000 rows earlier, with no row or column to
+    spare -- every one of its cells sits exactly on the pruning bound.  The strict test must keep all of them (the round-4
+    kernels cut such a path where it crossed a strip boundary at a slab corner: SW_PRUNE_MARGIN in csrc/sw_kernel_pk16.inc):
+    H of the last cell is the oracle's, with every strip height, with and without exact tracking, with and without the window."""
+    from masa_cudalign_amd.engine import SMITH_WATERMAN, F_NO_WINDOW
+    import time
+    s0, s1 = _pairs(pkg, "ties")
+    M, N = 36864, 12864                      # second copy: rows 24 000 ..., so (M, N) ends its first 12 864 columns
+    ref = oracle.stage1(s0[:M], s1[:N], want_last_row=True)
+    want = int(ref["last_row"][-1, 0])
+    assert want == ref["best"][2] and ref["best"][0] < M        # the same score, reached far above by the first copy (the canonical cell)
+    part = pkg.Partition(0, 0, M, N)
+    for R in (4, 8, 16, 32):
+        for flags in (0, F_NO_WINDOW):
+            for track in (False, True):
+                al = pkg.MI355Aligner(device=0, rows_per_lane=R, flags=flags)
+                try:
+                    al.setSequences(s0, s1)
+                    al.streamBegin(part, track_best=track, prune_blocks=True, want_last_row=True)
+                    while not al.streamPoll()[1]:
+                        time.sleep(0.001)
+                    lr = al.streamReadLastRow()
+                    best, _ = al.streamEnd()
+                    st = al.getStatistics()
+                finally:
+                    al.close()
+                assert int(lr[-1, 0]) == want, (R, flags, track, lr[-1], want)
+                assert np.all(lr <= ref["last_row"][1:]) and st["pruned_cells"] > 0.3 * M * N
+                if track:
+                    assert (best[0] + 1, best[1] + 1, best[2]) == tuple(ref["best"])
