@@ -13,7 +13,10 @@ R = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 nw = len(sys.argv) > 4 and sys.argv[4] == "nw"
 s0, s1 = pkg.seqgen.related_pair(m, n, cfg=5)
 part = pkg.Partition(0, 0, m, n)
-for name, flags, prune in (("unpruned", 0, False), ("window", 0, True), ("no window", F_NO_WINDOW, True), ("window", 0, True), ("no window", F_NO_WINDOW, True)):
+runs = (("unpruned", 0, False), ("window", 0, True), ("no window", F_NO_WINDOW, True), ("window", 0, True), ("no window", F_NO_WINDOW, True))
+if os.environ.get("PROBE_WINDOW_ONLY"):
+    runs = (("window", 0, True), ("window", 0, True))
+for name, flags, prune in runs:
     al = pkg.MI355Aligner(device=0, rows_per_lane=R, flags=flags)
     al.setSequences(s0, s1)
     t0 = time.time()
