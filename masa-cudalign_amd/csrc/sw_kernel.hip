@@ -99,11 +99,11 @@ struct LaneState {
 };
 
 // One systolic step: every lane advances one column.  `u` is the step index inside the chunk.
-template <int R, bool SW, bool PROFILE, bool MASKED, bool TRACK, bool EMIT_ANY>
+template <int R, bool SW, bool PROFILE, bool MASKED, bool TRACK, bool EMIT_ANY, bool CMAX = false>
 __device__ __forceinline__ void wave_step(LaneState<R>& st, WaveLds* lds, const int u, const int lane,
                                           const int jl /* column of this lane at u=0 */, const int n,
                                           const int nvalid, const int emit_lane, const int emit_row,
-                                          int2& feed_io, int& c1_io) {
+                                          int2& feed_io, int& c1_io, int* cmax = nullptr) {
     // ---- hand-off from the lane above (full EXEC); LDS reads are software-pipelined by one step ----
     const int2 feed = feed_io;                             // (t,F) of the row above: lane 0 only
     const int c1 = c1_io;
@@ -137,13 +137,14 @@ __device__ __forceinline__ void wave_step(LaneState<R>& st, WaveLds* lds, const 
             st.e[r] = E;
             upt = t;
             upf = F;
-            if (TRACK) { if (r & 1) mx = max3(mx, tprev, t); tprev = t; }
+            if (TRACK || CMAX) { if (r & 1) mx = max3(mx, tprev, t); tprev = t; }
             if (EMIT_ANY) {
                 t_emit = (r == emit_row) ? t : t_emit;
                 f_emit = (r == emit_row) ? F : f_emit;
             }
         }
-        if (TRACK && (R & 1)) mx = max(mx, tprev);
+        if ((TRACK || CMAX) && (R & 1)) mx = max(mx, tprev);
+        if (CMAX) *cmax = max(*cmax, mx);                   // the lane's maximum over the chunk (block pruning: what it can hand on)
         st.tup_prev = tup;
         st.tbot = upt;
         st.fbot = upf;
@@ -167,7 +168,13 @@ __device__ __forceinline__ void wave_step(LaneState<R>& st, WaveLds* lds, const 
     }
 }
 
-template <int R, bool SW, bool PROFILE, bool TRACK>
+// PRUNE (round 5; local alignments): block pruning in the int32 family too -- the reference prunes in every instantiation of
+// its kernels (X/CUDAligner.cu:950-960); here a 64-step slab of the strip is skipped when nothing that enters it (the lanes'
+// chunk maxima, the bus cells above it) can still reach the running best, exactly the packed kernel's local test
+// (sw_kernel_pk16.inc, SW_PRUNE_MARGIN included).  Skipped cells read H = 0, E = F = -INF.  No window, no fast-forward: this
+// family takes the pairs the packed kernel cannot (more than 14 common byte values) and its reruns.
+#define SW32_PRUNE_MARGIN 8
+template <int R, bool SW, bool PROFILE, bool TRACK, bool PRUNE = false>
 __device__ __attribute__((noinline)) void process_strip(const KernelArgs* ap, const int s_in, WaveLds* lds, const int lane) {
     const UniformArgs a = uniform_args(ap);
     const int s = __builtin_amdgcn_readfirstlane(s_in);
@@ -234,11 +241,19 @@ __device__ __attribute__((noinline)) void process_strip(const KernelArgs* ap, co
     }
     st.tbot = NEG_INF; st.fbot = NEG_INF;
     st.best_t = NEG_INF; st.best_r = R; st.best_j = -1;
+    // block pruning: what the lane holds, bounded from above (t domain); the running best as of the last look
+    int lane_entry = NEG_INF, gseen = NEG_INF, pruned_slabs = 0;
+    if (PRUNE) {
+#pragma unroll
+        for (int r = 0; r < R; r++) lane_entry = max(lane_entry, st.tl[r]);
+    }
+    const int pr_rows = PRUNE ? a->prune_rows - 1 - row0 : 0, pr_cols = PRUNE ? a->prune_cols - 1 : 0;
 
     DBG(1, 1);
     // ---- sweep the strip ----
     for (int c = 0; c < nchunks; c++) {
         const int col0 = c * CHUNK;
+        bool skip = false;
         DBG(2, c); DBG(3, 10);
         // (1) input chunk: wait for the strip above, then stage bus + seq1 codes into LDS
         {
@@ -259,6 +274,15 @@ __device__ __attribute__((noinline)) void process_strip(const KernelArgs* ap, co
                 hf = ld_agent2(&a->bus[col]);
                 code = a->seq1[col];
             }
+            if (PRUNE) {
+                gseen = max(gseen, poll_agent(a->gbest_in));
+                if (!ragged && col0 >= 2 * CHUNK && col0 + CHUNK <= n) {
+                    // (lane k is k columns behind lane 0: the slab touches columns col0 - 63 .. col0 + 63)
+                    const int left = min(pr_rows + 2, pr_cols + 1 - (col0 - CHUNK));
+                    const int e = max(lane_entry, hf.x - GAP_FIRST);
+                    skip = !__any(e + left + SW32_PRUNE_MARGIN >= gseen);
+                }
+            }
             // shift the seq1 window: [64,128) -> [0,64), then the new chunk
             const unsigned char prev = lds->c1[CHUNK + lane];
             lds->c1[lane] = prev;
@@ -274,18 +298,39 @@ __device__ __attribute__((noinline)) void process_strip(const KernelArgs* ap, co
         const bool masked = (c == 0) || (col0 + CHUNK - 1 >= n);
         int2 feed = lds->in_tf[0];
         int c1 = lds->c1[CHUNK - lane];
-        if (ragged) {
+        int cm = NEG_INF;
+        if (PRUNE && skip) {
+            // the slab is not computed: every cell in it counts as H = 0 (t = -5), E = F = -INF
+#pragma unroll
+            for (int r = 0; r < R; r++) { st.tl[r] = -GAP_FIRST; st.e[r] = NEG_INF; }
+            st.tup_prev = -GAP_FIRST; st.tbot = -GAP_FIRST; st.fbot = NEG_INF;
+            lds->out_tf[lane] = make_int2(-GAP_FIRST, NEG_INF);
+            cm = -GAP_FIRST;
+            pruned_slabs++;
+        } else if (ragged) {
 #pragma unroll 2
             for (int u = 0; u < CHUNK; u++)
-                wave_step<R, SW, PROFILE, true, TRACK, true>(st, lds, u, lane, jl, n, nvalid, emit_lane, emit_row, feed, c1);
+                wave_step<R, SW, PROFILE, true, TRACK, true, PRUNE>(st, lds, u, lane, jl, n, nvalid, emit_lane, emit_row, feed, c1, &cm);
         } else if (masked) {
 #pragma unroll 2
             for (int u = 0; u < CHUNK; u++)
-                wave_step<R, SW, PROFILE, true, TRACK, false>(st, lds, u, lane, jl, n, nvalid, 63, R - 1, feed, c1);
+                wave_step<R, SW, PROFILE, true, TRACK, false, PRUNE>(st, lds, u, lane, jl, n, nvalid, 63, R - 1, feed, c1, &cm);
         } else {
 #pragma unroll 4
             for (int u = 0; u < CHUNK; u++)
-                wave_step<R, SW, PROFILE, false, TRACK, false>(st, lds, u, lane, jl, n, nvalid, 63, R - 1, feed, c1);
+                wave_step<R, SW, PROFILE, false, TRACK, false, PRUNE>(st, lds, u, lane, jl, n, nvalid, 63, R - 1, feed, c1, &cm);
+        }
+        if (PRUNE) {
+            // what the lane can hand on (a chunk it sat out entirely -- masked steps -- keeps what it held), and what the others learn
+            lane_entry = max(cm, skip ? -GAP_FIRST : (masked ? lane_entry : NEG_INF));
+            if (!skip && __any(cm > gseen)) {
+                int w = cm;
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1) w = max(w, __shfl_xor(w, d));
+                w = __builtin_amdgcn_readfirstlane(w);
+                if (lane == 0) atomicMax(a->gbest, w);
+                gseen = max(gseen, w);
+            }
         }
         DBG(3, 30);
         // (3) output chunk: columns col0-emit_lane .. col0-emit_lane+63
@@ -310,6 +355,7 @@ __device__ __attribute__((noinline)) void process_strip(const KernelArgs* ap, co
         }
     }
 
+    if (PRUNE && pruned_slabs > 0 && lane == 0 && a->pruned_slabs != nullptr) atomicAdd(a->pruned_slabs, (unsigned long long) pruned_slabs);
     DBG(3, 40);
     // ---- strip epilogue: last column, best score ----
     if (a->last_col != nullptr) {
@@ -356,7 +402,7 @@ __device__ __attribute__((noinline)) void process_strip(const KernelArgs* ap, co
 #ifndef SW32_WAVES_PER_SIMD
 #define SW32_WAVES_PER_SIMD 2
 #endif
-template <int R, bool SW, bool PROFILE, bool TRACK>
+template <int R, bool SW, bool PROFILE, bool TRACK, bool PRUNE = false>
 __global__ void __launch_bounds__(64)
 #if SW32_WAVES_PER_SIMD == 2
 __attribute__((amdgpu_waves_per_eu(R == 16 ? 1 : 2, R == 16 ? 1 : 2)))
@@ -385,7 +431,7 @@ sw_strip_kernel(const KernelArgs* __restrict__ ap) {
             __builtin_amdgcn_wave_barrier();
             break;
         } else {
-            process_strip<R, SW, PROFILE, TRACK>(ap, s, lds, lane);
+            process_strip<R, SW, PROFILE, TRACK, PRUNE>(ap, s, lds, lane);
         }
         complete_strip_common(ap, s, lane, 64 * R, true);
     }
@@ -413,10 +459,13 @@ __global__ void fill_cells_kernel(int2* p, long long count, int2 value) {
 }
 
 template <int R>
-static hipError_t launch_r(const KernelArgs* a, int grid, hipStream_t stream, bool sw, bool profile, bool track) {
+static hipError_t launch_r(const KernelArgs* a, int grid, hipStream_t stream, bool sw, bool profile, bool track, bool prune) {
 #define LAUNCH(SWV, PRV, TRV) \
     hipLaunchKernelGGL((sw_strip_kernel<R, SWV, PRV, TRV>), dim3(grid), dim3(64), 0, stream, a)
-    if (sw) {
+    if (sw && prune) {        // block pruning: local alignments with their best score tracked
+        if (profile) hipLaunchKernelGGL((sw_strip_kernel<R, true, true, true, true>), dim3(grid), dim3(64), 0, stream, a);
+        else hipLaunchKernelGGL((sw_strip_kernel<R, true, false, true, true>), dim3(grid), dim3(64), 0, stream, a);
+    } else if (sw) {
         if (profile) { if (track) LAUNCH(true, true, true); else LAUNCH(true, true, false); }
         else         { if (track) LAUNCH(true, false, true); else LAUNCH(true, false, false); }
     } else {
@@ -433,10 +482,11 @@ hipError_t launch_strip_kernel(const KernelArgs& a, KernelArgs* dargs, int rows_
     if (e != hipSuccess) return e;
     e = hipStreamSynchronize(stream);      // `a` is a host temporary
     if (e != hipSuccess) return e;
+    const bool prune = a.prune != 0 && sw && track;
     switch (rows_per_lane) {
-    case 4: return launch_r<4>(dargs, grid, stream, sw, profile, track);
-    case 8: return launch_r<8>(dargs, grid, stream, sw, profile, track);
-    case 16: return launch_r<16>(dargs, grid, stream, sw, profile, track);
+    case 4: return launch_r<4>(dargs, grid, stream, sw, profile, track, prune);
+    case 8: return launch_r<8>(dargs, grid, stream, sw, profile, track, prune);
+    case 16: return launch_r<16>(dargs, grid, stream, sw, profile, track, prune);
     default: return hipErrorInvalidValue;
     }
 }

@@ -1,11 +1,9 @@
 """Where a strip's lifetime goes in a pruned run: fast-forward runs, skipped chunks the chunk body takes, computed chunks.
-Needs a library whose pruning kernels carry the instrumentation of tools/pk16_trace_band.patch (kept out of the tree: it
-would change the build id of the measured library):
-    git apply tools/pk16_trace_band.patch
-    (cd masa-cudalign_amd/csrc && ./hipcc_aligned.sh sw_kernel_pk16_f.hip _var/f_tb.o -O3 -std=c++17 -fPIC -w -mllvm -amdgpu-sched-strategy=max-ilp -DPK16_TRACE_BAND \
-      && hipcc --offload-arch=gfx950 -shared $(ls _obj/*.o | grep -v sw_kernel_pk16_f.o) _var/f_tb.o -o ../libvar_tb.so)
-    git checkout masa-cudalign_amd/csrc/sw_kernel_pk16.inc
-    MI355SW_LIB=$PWD/masa-cudalign_amd/libvar_tb.so MI355SW_TRACE=/tmp/tb.bin python tools/seed_probe.py 16000000 14650000 sw 5 nobase
+Needs a library whose R' = 16 pruning kernels were built with -DPK16_TRACE_BAND (a build of its own: the instrumentation
+switches the hot loop off):
+    (cd masa-cudalign_amd/csrc && mkdir -p _var && ./hipcc_aligned.sh sw_kernel_pk16_f.hip _var/f_tb.o -O3 -std=c++17 -fPIC -w -mllvm -amdgpu-sched-strategy=max-ilp -DPK16_TRACE_BAND \
+      && hipcc --offload-arch=gfx950 -shared $(ls _obj/*.o | grep -v sw_kernel_pk16_f.o) _var/f_tb.o -o ../../tools/_var_tb.so)
+    MI355SW_LIB=$PWD/tools/_var_tb.so MI355SW_TRACE=/tmp/tb.bin PROBE_WINDOW_ONLY=1 python tools/window_probe.py 16000000 14650000 32
     python tools/trace_band_split.py /tmp/tb.bin"""
 import sys, numpy as np
 t = np.fromfile(sys.argv[1], dtype=np.int64).reshape(-1, 4)
