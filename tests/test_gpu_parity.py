@@ -504,7 +504,8 @@ def test_stop_like_stage2_goal_found(pkg, oracle):
         al.close()
     got = mg.lastColumn()                    # corner cell + the rows dispatched before the stop
     seen = got.shape[0] - 1
-    assert stop_after <= seen < stop_after + 4 * st["strip_rows"]
+    # (the last-column cells travel in chunks of up to 16 strips -- runtime.cpp, AlignJob::pump -- and the stop is looked at between them)
+    assert stop_after <= seen < stop_after + 17 * st["strip_rows"]
     # rows 0..seen of the matrix do not depend on anything below them
     ref = oracle.stage1(s0[:seen], s1, recurrence=oracle.NEEDLEMAN_WUNSCH, first_row_type=oracle.INIT_WITH_GAPS,
                         first_col_type=oracle.INIT_WITH_GAPS, best_mode=oracle.BEST_LAST_CELL,

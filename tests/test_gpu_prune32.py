@@ -53,6 +53,8 @@ def test_int32_family_prunes_and_keeps_the_oracles_best(pkg, oracle, mode):
             mgp = out[True][2]
             assert np.all(mgp.lastRow() <= ref["last_row"]) and np.all(mgp.lastColumn() <= ref["last_col"])
             for i in sorted(mgp.special_rows):
+                if i not in want_rows:                  # (the manager keeps the last row under its row number too)
+                    continue
                 got, want = mgp.specialRow(i), want_rows[i]
                 assert np.all(got <= want) and np.all(got[1:, 0] >= 0), i
                 if i <= ref["best"][0]:

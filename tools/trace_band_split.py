@@ -2,8 +2,8 @@
 Needs a library whose R' = 16 pruning kernels were built with -DPK16_TRACE_BAND (a build of its own: the instrumentation
 switches the hot loop off):
     (cd masa-cudalign_amd/csrc && mkdir -p _var && ./hipcc_aligned.sh sw_kernel_pk16_f.hip _var/f_tb.o -O3 -std=c++17 -fPIC -w -mllvm -amdgpu-sched-strategy=max-ilp -DPK16_TRACE_BAND \
-      && hipcc --offload-arch=gfx950 -shared $(ls _obj/*.o | grep -v sw_kernel_pk16_f.o) _var/f_tb.o -o ../../tools/_var_tb.so)
-    MI355SW_LIB=$PWD/tools/_var_tb.so MI355SW_TRACE=/tmp/tb.bin PROBE_WINDOW_ONLY=1 python tools/window_probe.py 16000000 14650000 32
+      && hipcc --offload-arch=gfx950 -shared $(ls _obj/*.o | grep -v sw_kernel_pk16_f.o) _var/f_tb.o -o ../libvar_tb.so)
+    MI355SW_LIB=$PWD/masa-cudalign_amd/libvar_tb.so MI355SW_TRACE=/tmp/tb.bin PROBE_WINDOW_ONLY=1 python tools/window_probe.py 16000000 14650000 32
     python tools/trace_band_split.py /tmp/tb.bin"""
 import sys, numpy as np
 t = np.fromfile(sys.argv[1], dtype=np.int64).reshape(-1, 4)
