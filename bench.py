@@ -481,6 +481,7 @@ def main():
         mine = {"rank": rank, "device": local_rank, "name": prop.name,
                 "pci_bus_id": getattr(prop, "pci_bus_id", None), "pci_device_id": getattr(prop, "pci_device_id", None),
                 "band_columns": [j0, j1], "kernel_ms": sum(kernel_ms) / len(kernel_ms),
+                "seed_ms": st.get("seed_ms", 0.0),            # the pass that gave the chain's pruning bound its first value (band 0 runs it), outside kernel_ms
                 "wait_for_left_neighbour_ms": sum(wait_ms) / len(wait_ms),      # per wavefront, in claim_strip_common
                 "pruned_cells": sum(pruned) / len(pruned), "restarts": runner.restarts, "p2p_error": runner.p2p_error}
         ranks = [None] * world

@@ -235,7 +235,7 @@ class Stage1Manager:
     def __init__(self, partition, alignment_start=AT_ANYWHERE, alignment_end=AT_ANYWHERE,
                  special_row_interval=0, keep_last_row=False, keep_last_column=False,
                  first_row_reader=None, first_column_reader=None, seq0_offset=0, seq1_offset=0,
-                 super_partition=None, block_pruning=False, sra_partition=None, status=None, max_alignments=1):
+                 super_partition=None, block_pruning=False, sra_partition=None, status=None, max_alignments=1, prune_global=True):
         self.partition = partition
         self.super_partition = super_partition or partition
         self.seq0_offset, self.seq1_offset = seq0_offset, seq1_offset
@@ -264,8 +264,11 @@ class Stage1Manager:
         # sw_stage1.cpp:219-225: pruning only when the alignment may end anywhere -- and, beyond the reference's stage 1
         # (which holds the bound, AbstractBlockPruning.cpp:92-109, but never asks for it), for global alignments: both
         # ends in the corners, the goal is the last cell
+        # (prune_global=False: the reference's own rule only -- what stage1.py / pipeline.py / tools/align_fasta.py pass unless
+        #  asked otherwise, like the adapter's --prune-global: a pruned global stage 1 leaves lower bounds in its special rows,
+        #  a work directory that is no longer value-compatible with one the reference wrote)
         self.block_pruning = block_pruning and (alignment_end == AT_ANYWHERE or
-                                                (alignment_start == AT_SEQUENCE_1_AND_2 and alignment_end == AT_SEQUENCE_1_AND_2))
+                                                (prune_global and alignment_start == AT_SEQUENCE_1_AND_2 and alignment_end == AT_SEQUENCE_1_AND_2))
         # special rows / last row go to disk when a SpecialRowsPartition is given (AlignerManager::dispatchRow ->
         # SpecialRowsPartition::write, AlignerManager.cpp:334-356); the status file follows every completed row
         self.sra, self.status = sra_partition, status

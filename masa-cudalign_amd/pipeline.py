@@ -53,7 +53,7 @@ def check_work_directory(work, seq0, seq1):
 
 @sra_mod.with_async_files
 def align(aligner, seq0, seq1, work, alignment_start=AT_ANYWHERE, alignment_end=AT_ANYWHERE, sra_limit=0,
-          block_pruning=True, max_partition_size=16, progress=None, max_alignments=1, ram_limit=0):
+          block_pruning=True, max_partition_size=16, progress=None, max_alignments=1, ram_limit=0, prune_global=False):
     """seq0, seq1: fasta.Sequence.  Returns {"best", "alignment": stage56.Alignment or None, "text": bytes of
     alignment.00.txt or None when nothing scored above the floor, "crosspoints": {2: n, 3: n, 4: n},
     "seconds": {stage: s}}; with max_alignments > 1 also "alignments": one such record per end point stage 1 kept
@@ -68,7 +68,7 @@ def align(aligner, seq0, seq1, work, alignment_start=AT_ANYWHERE, alignment_end=
     t = time.time()
     r1 = stage1(aligner, d0, d1, work, alignment_start=alignment_start, alignment_end=alignment_end, sra_limit=sra_limit,
                 block_pruning=block_pruning, bounds=bounds, progress=progress, max_alignments=max_alignments,
-                ram_limit=ram_limit, areas=areas)
+                ram_limit=ram_limit, areas=areas, prune_global=prune_global)
     secs[1] = time.time() - t
     out = {"best": r1["best"], "alignment": None, "text": None, "crosspoints": {}, "seconds": secs, "stage1": r1,
            "alignments": []}

@@ -55,7 +55,31 @@ class _FileQueue:
     def _enabled(self):
         return self.depth > 0 and not os.environ.get("MI355SW_SRA_SYNC")
 
+    def _after_fork(self):
+        """a child process inherits a snapshot of the parent's queue and a condition variable in whatever state it was: the
+        parent carries its operations out, the child starts empty"""
+        if self.pid is not None and self.pid != os.getpid():
+            self.cv = threading.Condition()
+            self.q = collections.deque()
+            self.bytes = 0
+            self.running = None
+            self.pending = {}
+            self.error = None
+            self.thread = None
+            self.pid = None
+
+    def _check_alive(self):
+        """operations are pending and nobody is left to carry them out (the thread died: an exception outside an operation,
+        interpreter shutdown): say so instead of returning as if the files were in place"""
+        if self.pending and (self.thread is None or not self.thread.is_alive()):
+            n = sum(self.pending.values())
+            self.q.clear()
+            self.pending.clear()
+            self.bytes = 0
+            raise RuntimeError("special rows area: %d queued file operations were never carried out (the file thread is gone)" % n)
+
     def submit(self, owner, fn, *args, nbytes=0):
+        self._after_fork()
         if not self._enabled():
             self.drain()
             fn(*args)
@@ -104,6 +128,7 @@ class _FileQueue:
 
     def wait(self, owner):
         """until every operation asked for on behalf of `owner` has been carried out"""
+        self._after_fork()
         if self.pid != os.getpid():
             return
         with self.cv:
@@ -111,8 +136,11 @@ class _FileQueue:
                 self.cv.wait(1.0)
             if self.error is not None:
                 self._raise()
+            if self.pending.get(id(owner), 0) > 0:
+                self._check_alive()
 
     def drain(self):
+        self._after_fork()
         if self.pid != os.getpid():
             return
         with self.cv:
@@ -120,6 +148,10 @@ class _FileQueue:
                 self.cv.wait(1.0)
             if self.error is not None:
                 self._raise()
+            self._check_alive()
+
+    def has_pending(self):
+        return bool(self.pending)
 
 
 _files = _FileQueue()
@@ -311,6 +343,10 @@ class SpecialRowsPartition:
             if not os.path.isdir(self.path):
                 raise RuntimeError("special rows partition %s does not exist" % self.path)
         else:
+            # (a queued rename of a directory may target this very path -- the same stage run again in one work directory:
+            #  _move_directory would find the directory made here and remove it before renaming over it)
+            if _files.has_pending():
+                _files.drain()
             os.makedirs(os.path.dirname(self.path), exist_ok=True)
             try:
                 os.mkdir(self.path)

@@ -70,8 +70,10 @@ def _crosspoints_on_disk(work):
 @sra_mod.with_async_files
 def stage1(aligner, seq0, seq1, work, alignment_start=AT_ANYWHERE, alignment_end=AT_ANYWHERE, sra_limit=0,
            block_pruning=True, manager_class=Stage1Manager, bounds=None, progress=None, progress_interval=2.0,
-           max_alignments=1, ram_limit=0, areas=None):
-    """Runs (or resumes) stage 1 of seq0 x seq1 in work directory `work`.  `aligner` is an MI355Aligner; create it
+           max_alignments=1, ram_limit=0, areas=None, prune_global=False):
+    """Runs (or resumes) stage 1 of seq0 x seq1 in work directory `work`.  `prune_global`: block pruning for a GLOBAL alignment
+    too (both ends in the corners) -- beyond the reference, whose stage 1 prunes local alignments only (sw_stage1.cpp:219-225);
+    the adapter's --prune-global.  `aligner` is an MI355Aligner; create it
     with a fixed strip height (rows_per_lane) when the area must be resumable or shared with CUDAlign: special rows
     sit on multiples of the strip height (1024 or 2048 rows give CUDAlign's 8192-row spacing).
     `bounds` = (i0, j0, i1, j1): the part of the matrix --trim selects (Sequence::getTrimStart()-1 .. getTrimEnd(),
@@ -132,7 +134,7 @@ def stage1(aligner, seq0, seq1, work, alignment_start=AT_ANYWHERE, alignment_end
     rel = Partition(i0 - bi0, 0, bi1 - bi0, bj1 - bj0)
     mgr = manager_class(part, alignment_start=alignment_start, alignment_end=alignment_end,
                         special_row_interval=interval, first_row_reader=fr, first_column_reader=fc,
-                        super_partition=sup, block_pruning=block_pruning,
+                        super_partition=sup, block_pruning=block_pruning, prune_global=prune_global,
                         sra_partition=part_sra, status=status, seq0_offset=bi0, seq1_offset=bj0,
                         **({"max_alignments": max_alignments} if max_alignments != 1 else {}))
     if status.loaded and status.best is not None and status.best[0] >= 0:

@@ -27,7 +27,7 @@ CASES = {
     # GLOBAL alignment (--alignment-edges=++), stage 1 with block pruning -- the reference run of the fixture did not prune
     # (its stage 1 never does for global alignments); special rows off the optimal paths are lower bounds here
     "global_pruned_60000x50000": ("full_pipeline_global_60000x50000_b8192", dict(rows_per_lane=16),
-                                  dict(sra_limit=4 * 1024 * 1024, block_pruning=True, alignment_start=4, alignment_end=4), True),
+                                  dict(sra_limit=4 * 1024 * 1024, block_pruning=True, prune_global=True, alignment_start=4, alignment_end=4), True),
     "global_unpruned_60000x50000": ("full_pipeline_global_60000x50000_b8192", dict(rows_per_lane=16),
                                     dict(sra_limit=4 * 1024 * 1024, block_pruning=False, alignment_start=4, alignment_end=4), True),
 }

@@ -286,3 +286,39 @@ def test_file_operations_inline_on_request(pkg, tmp_path, monkeypatch):
         p = sra.SpecialRowsPartition(os.path.join(str(tmp_path), "a"), 0, 0, 100, 9)
         assert p.write(50, np.zeros((10, 2), dtype=np.int32)) is True
         assert os.listdir(p.path) == ["00000032"] and not sra._files.pending
+
+
+def test_file_queue_says_when_nobody_is_left_to_carry_out_its_operations(pkg):
+    """wait()/drain() used to return silently when the file thread was gone with operations pending: the files a
+    caller then reads were never written"""
+    from masa_cudalign_amd import sra as sra_mod
+    q = sra_mod._FileQueue()
+    owner = object()
+    q.pid = os.getpid()
+    q.pending[id(owner)] = 2                   # two operations queued, the thread that would carry them out never started / died
+    with pytest.raises(RuntimeError, match="never carried out"):
+        q.drain()
+    assert not q.pending
+    q.pending[id(owner)] = 1
+    with pytest.raises(RuntimeError, match="never carried out"):
+        q.wait(owner)
+
+
+def test_file_queue_starts_empty_in_a_forked_child(pkg):
+    """a child process inherits a snapshot of the parent's queue: it must neither repeat the parent's operations nor wait on
+    the parent's condition variable"""
+    from masa_cudalign_amd import sra as sra_mod
+    q = sra_mod._FileQueue()
+    q.pid = os.getpid() + 1                    # "another process's" queue, as a fork leaves it
+    q.pending[1] = 3
+    q.q.append((None, lambda: None, (), 0))
+    cv = q.cv
+    q.drain()                                  # resets, then has nothing to wait for
+    assert not q.pending and not q.q and q.pid is None and q.cv is not cv
+    done = []
+    with sra_mod.async_files():
+        pass
+    q.depth = 1
+    q.submit(None, done.append, 1)             # and works: a thread of this process is started
+    q.drain()
+    assert done == [1]

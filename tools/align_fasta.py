@@ -8,7 +8,7 @@ MI355X) behind the handful of MASA-CUDAlign options that concern the path -- not
       --trim=I0,I1,J0,J1  --reverse=1|2|both  --complement=1|2|both  --reverse-complement=1|2|both  --clear-n
       --alignment-edges=XY      X start, Y end: * anywhere (local), 1 / 2 on that sequence's edge, 3 on either, + on both (global)
       --max-alignments=N        trace back up to N different alignments (alignment.00.txt .. alignment.NN.txt)
-      --no-block-pruning  --gpu=ID  --stage-1 (best score only)
+      --no-block-pruning  --prune-global (block pruning for a global alignment too)  --gpu=ID  --stage-1 (best score only)
 
 Prints one JSON line (best score, crosspoints per stage, seconds per stage) and leaves alignment.00.txt in the work
 directory.  The engine has no CPU fallback: without an MI355X this fails with MI355SW_ENOGPU."""
@@ -36,6 +36,7 @@ def main(argv):
             "+": pkg.AT_SEQUENCE_1_AND_2}
     work, limit, device, prune, only1, edges, count, ram = "./work.tmp", None, 0, True, False, "**", 1, 0
     trim, rev, comp, clear_n = [0, 0, 0, 0], [False, False], [False, False], False
+    prune_global = False
     files = []
     for a in argv:
         if a.startswith("--work-dir="):
@@ -60,6 +61,8 @@ def main(argv):
             count = int(a[17:])
         elif a == "--no-block-pruning":
             prune = False
+        elif a == "--prune-global":
+            prune_global = True
         elif a.startswith("--gpu="):
             device = int(a[6:])
         elif a == "--stage-1":
@@ -80,11 +83,12 @@ def main(argv):
             bounds = (seqs[0].offset0 - 1, seqs[1].offset0 - 1, seqs[0].offset1, seqs[1].offset1)
             r = stage1.stage1(al, seqs[0].data(), seqs[1].data(), work, alignment_start=edge[edges[0]],
                               alignment_end=edge[edges[1]], sra_limit=limit, block_pruning=prune, bounds=bounds,
-                              progress=sys.stderr, max_alignments=count, ram_limit=ram)
+                              progress=sys.stderr, max_alignments=count, ram_limit=ram, prune_global=prune_global)
             res = {"best": list(r["best"]), "seconds": {"1": r["seconds"]}, "gcups": r["gcups"]}
         else:
             out = pipeline.align(al, seqs[0], seqs[1], work, alignment_start=edge[edges[0]], alignment_end=edge[edges[1]],
-                                 sra_limit=limit, block_pruning=prune, progress=sys.stderr, max_alignments=count, ram_limit=ram)
+                                 sra_limit=limit, block_pruning=prune, progress=sys.stderr, max_alignments=count, ram_limit=ram,
+                                 prune_global=prune_global)
             res = {"best": list(out["best"]), "seconds": {str(k): v for k, v in out["seconds"].items()},
                    "crosspoints": {str(k): v for k, v in out["crosspoints"].items()},
                    "alignments": [os.path.join(work, "alignment.%02d.txt" % k) for k in range(len(out["alignments"]))]}
