@@ -248,3 +248,33 @@ def test_a_co_optimal_path_that_can_only_tie_survives_pruning(pkg, oracle):
                 assert np.all(lr <= ref["last_row"][1:]) and st["pruned_cells"] > 0.3 * M * N
                 if track:
                     assert (best[0] + 1, best[1] + 1, best[2]) == tuple(ref["best"])
+
+
+def test_chromosome_like_pair_with_leading_n_runs(pkg, oracle):
+    """two "chromosomes" that start with unsequenced stretches of different length (runs of N, upper-cased FASTA bytes as the
+    reference compares them: N scores a match against N, X/CUDAligner.cu:276-289) before their homology begins: nothing related
+    at the left edge of the matrix beyond the N block, five letters in play (the permute scoring of the packed kernel only
+    takes chunks of plain A/C/G/T).  Default configuration, pruning on: the oracle's best cell, and a good part of the matrix
+    skipped."""
+    from helpers import oracle_full
+    sg = pkg.seqgen
+    body0 = sg.random_dna(sg.SEED0 + 510, 120000)
+    body1 = sg.mutate_dna(body0, sg.SEED1 + 510, inversion=0.0)[:110000]
+    s0 = np.ascontiguousarray(np.concatenate([np.full(30000, ord("N"), dtype=np.uint8), body0]))
+    s1 = np.ascontiguousarray(np.concatenate([np.full(18000, ord("N"), dtype=np.uint8), body1]))
+    m, n = len(s0), len(s1)
+    ref = oracle_full(oracle, s0, s1)
+    al = pkg.MI355Aligner(device=0)
+    try:
+        al.setSequences(s0, s1)
+        part = pkg.Partition(0, 0, m, n)
+        res = {}
+        for prune in (False, True):
+            mg = pkg.Stage1Manager(part, block_pruning=prune)
+            al.alignPartition(part, mg)
+            res[prune] = (tuple(mg.getBestScore()), al.getStatistics())
+        assert res[False][0] == res[True][0] == tuple(ref["best"])
+        assert res[True][1]["profile_kernel"] == 2 and res[True][1]["restarts"] == 0
+        assert res[True][1]["pruned_cells"] > 0.2 * m * n, res[True][1]
+    finally:
+        al.close()
