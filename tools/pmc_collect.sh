@@ -8,7 +8,7 @@ tag=${1:-r02}
 out=gpurun_out/prof_$tag
 mkdir -p $out
 export TMPDIR=/tmp
-BENCH="python3 bench.py --no-cpu-baseline --no-target-shape --no-shapes"
+BENCH="python3 bench.py --no-cpu-baseline --no-target-shape --no-shapes --no-c3-full"
 rocprofv3 --kernel-trace --stats -d $out/stats -- $BENCH --steps 3 --warmup 1 > $out/bench_stats.json 2> $out/bench_stats.err
 python3 tools/rocpd_summary.py stats $(find $out/stats -name '*.db' | head -1) $out/${tag}_pk16_kernel_stats.csv $out/${tag}_pk16_kernel_dispatches.csv > /dev/null
 rocprofv3 --pmc FETCH_SIZE -d $out/fetch -- $BENCH --steps 1 --warmup 0 > $out/bench_fetch.json 2> $out/bench_fetch.err

@@ -22,7 +22,11 @@ def main(tag):
                          % (tag, cfg["kernel_build_id"], bench.kernel_build_id()))
     hbm = json.load(open(os.path.join(prof, "%s_pk16_hbm_pmc.json" % tag)))
     sq = json.load(open(os.path.join(prof, "%s_pk16_sq_pmc.json" % tag)))
-    dom = max(hbm["counters"], key=lambda k: hbm["counters"][k].get("WRITE_SIZE", 0))
+    # the kernel of the bench line (the profiler prints template arguments with a space after every comma); the profiled command
+    # may have run other kernels too (fills, the seed pass)
+    want = cfg["kernel_name"].replace(" ", "")
+    named = [k for k in hbm["counters"] if want in k.replace(" ", "")]
+    dom = named[0] if named else max(hbm["counters"], key=lambda k: hbm["counters"][k].get("WRITE_SIZE", 0))
     fetch, write = hbm["counters"][dom]["FETCH_SIZE"], hbm["counters"][dom]["WRITE_SIZE"]
     traffic = (2.0 * fetch + write) * 1024.0
     valu = sq["counters"][dom]["SQ_INSTS_VALU"]
