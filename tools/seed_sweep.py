@@ -1,4 +1,4 @@
-"""The diagonal seed over pairs of different make: python tools/seed_sweep.py [out.json]
+"""The seed (round 5: anchored; MI355SW_STAIRCASE_SEED=1: round 4's staircase) over pairs of different make: python tools/seed_sweep.py [out.json]
 For each pair (seqgen.related_pair with other mutation rates, inverted segments of other sizes, none at all, unequal lengths)
 one pruning run that starts from the seed's bound and one that starts from nothing: the answers must be equal (best cell of
 the local alignment / H[m][n] of the global one), the seed must be a score that exists (<= the answer), and the record says
@@ -17,7 +17,33 @@ CASES = [
     (9000000, 8500000, 11, dict(inversion=0.15)),
     (10000000, 8500000, 13, dict(p_indel=0.01, indel_mean=8.0)),
     (8500000, 9500000, 17, dict(p_sub=0.08, inversion=0.02)),
+    # round 5 (the anchored seed: anchors from stripes, segments in bands of +-64 Ki columns around straight lines)
+    (9000000, 8800000, 19, dict(special="big_indels")),       # a 40 000-base insertion at 40 % and a 30 000-base deletion at 70 % of seq1
+    (9000000, 8800000, 23, dict(special="duplication")),      # a 100 000-base segment of seq0 copied into seq1 a second time, at its middle
+    (9000000, 8800000, 29, dict(special="late_start")),       # seq1 starts with 2.5 M unrelated bases: nothing aligns at the left edge
+    (26000000, 24000000, 31, {}),                             # enough columns for five anchors
 ]
+
+
+def make_pair(m, n, cfg, kw):
+    import numpy as np
+    sg = pkg.seqgen
+    special = kw.get("special")
+    if special is None:
+        return sg.related_pair(m, n, cfg=cfg, **kw)
+    s0 = sg.random_dna(sg.SEED0 + cfg, m)
+    base = sg.mutate_dna(s0, sg.SEED1 + cfg, inversion=0.0)
+    if special == "big_indels":
+        a, b = int(0.4 * n), int(0.7 * n)
+        s1 = np.concatenate([base[:a], sg.random_dna(77 + cfg, 40000), base[a:b], base[b + 30000:]])
+    elif special == "duplication":
+        a = n // 2
+        s1 = np.concatenate([base[:a], base[1000000:1100000], base[a:]])
+    else:
+        s1 = np.concatenate([sg.random_dna(78 + cfg, 2500000), base])
+    if len(s1) < n:
+        s1 = np.concatenate([s1, sg.random_dna(79 + cfg, n - len(s1))])
+    return s0, np.ascontiguousarray(s1[:n])
 
 
 def sweep(al, part, n, kind, bound):
@@ -39,8 +65,11 @@ def sweep(al, part, n, kind, bound):
 
 out = {"cases": []}
 os.environ["MI355SW_NO_DIAGONAL_SEED"] = "1"           # the sweeps below start from the bound they are given, or from nothing
-for m, n, cfg, kw in CASES:
-    s0, s1 = pkg.seqgen.related_pair(m, n, cfg=cfg, **kw)
+only = [int(x) for x in os.environ.get("SEED_SWEEP_CASES", "").split(",") if x]       # e.g. SEED_SWEEP_CASES=2,6: those cases only
+for idx, (m, n, cfg, kw) in enumerate(CASES):
+    if only and idx not in only:
+        continue
+    s0, s1 = make_pair(m, n, cfg, kw)
     al = pkg.MI355Aligner(device=0)
     al.setSequences(s0, s1)
     part = pkg.Partition(0, 0, m, n)
