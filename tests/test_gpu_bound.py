@@ -278,3 +278,32 @@ def test_chromosome_like_pair_with_leading_n_runs(pkg, oracle):
         assert res[True][1]["pruned_cells"] > 0.2 * m * n, res[True][1]
     finally:
         al.close()
+
+
+def test_anchored_seed_and_staircase_seed_agree_with_the_run_behind_them(pkg):
+    """9 M x 8.5 M related pair (one inverted segment): the anchored seed (segments between anchors, side by side) and round 4's
+    staircase (MI355SW_F_STAIRCASE_SEED: one chain of tiles) are two routes to a first bound -- both the score of an alignment
+    that exists, on this pair both the answer itself -- and the pruned run behind either reports the same best cell as the run
+    that starts from nothing (MI355SW_F_NO_DIAGONAL_SEED) while skipping far more."""
+    from masa_cudalign_amd.engine import SMITH_WATERMAN, F_STAIRCASE_SEED, F_NO_DIAGONAL_SEED
+    m, n = 9000000, 8500000
+    s0, s1 = pkg.seqgen.related_pair(m, n, cfg=5)
+    part = pkg.Partition(0, 0, m, n)
+    res = {}
+    for name, flags in (("anchored", 0), ("staircase", F_STAIRCASE_SEED), ("none", F_NO_DIAGONAL_SEED)):
+        al = pkg.MI355Aligner(device=0, flags=flags)
+        try:
+            al.setSequences(s0, s1)
+            seed = al.seedBound(part, SMITH_WATERMAN)
+            mg = pkg.Stage1Manager(part, block_pruning=True)
+            al.alignPartition(part, mg)
+            st = al.getStatistics()
+            res[name] = (seed, tuple(mg.getBestScore()), st["pruned_cells"] / float(m) / n, st["seed_ms"])
+        finally:
+            al.close()
+    assert res["none"][0] is None and res["none"][3] == 0
+    assert res["anchored"][1] == res["staircase"][1] == res["none"][1]
+    best = res["none"][1][2]
+    assert res["anchored"][0] == res["staircase"][0] == best
+    assert res["anchored"][3] > 0 and res["staircase"][3] > 0
+    assert min(res["anchored"][2], res["staircase"][2]) > res["none"][2] + 0.2
