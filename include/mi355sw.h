@@ -181,7 +181,8 @@ typedef struct {
     int32_t strip_rows_second;
     int32_t restarts;           /* reruns on the int32 kernels after an overflow report of the packed one */
     int32_t reserved_;
-    double seed_ms;             /* wall time of the diagonal seed pass that gave a pruning run of a large matrix its first
+    double seed_ms;             /* wall time of the seed pass (ABI 7: anchors from column stripes + the segments between them swept side
+                                   by side in band mode; MI355SW_F_STAIRCASE_SEED or no anchors: a staircase of tiles) that gave a pruning run of a large matrix its first
                                    bound (0: none ran): a staircase of tiles along the diagonal, swept before the main
                                    launch; the score it finds is a real alignment's, so the bound is valid whatever it is */
     char kernel[64];            /* the kernel instantiation of the (last) main launch, as the profiler names it without
@@ -308,7 +309,8 @@ typedef struct {
 } mi355sw_stream_params;
 
 int mi355sw_stream_begin(mi355sw_handle* h, const mi355sw_partition* partition, const mi355sw_stream_params* p);
-/* The diagonal seed pass on its own, for callers that divide one matrix among several streams (a chain of column bands, one GPU
+/* The seed pass on its own (a first value for the pruning bound: the score of an alignment the pass really finds along the
+ * diagonal of the pair's alignment -- see mi355sw_stats.seed_ms), for callers that divide one matrix among several streams (a chain of column bands, one GPU
  * each: a band cannot make the seed of the whole matrix, and mi355sw_stream_begin leaves it out for streams with column ports
  * or a streamed first column).  `partition` = the WHOLE matrix, borders as the run will have them: zeroes for SMITH_WATERMAN,
  * gap penalties from the origin for NEEDLEMAN_WUNSCH (a global alignment).  *have_bound = 1 and *bound = the value for
