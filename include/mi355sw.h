@@ -107,6 +107,10 @@ typedef struct {
                                                skipped cell (A/B measurements, tests) */
 #define MI355SW_F_STAIRCASE_SEED 2048       /* the diagonal seed as ONE chain of tiles down the diagonal (the round-4 form) instead of
                                                segments between anchors swept side by side (A/B measurements, tests) */
+#define MI355SW_F_GENERATE_GAP_COLUMNS 4096  /* mi355sw_align_partition makes a gap-initialised first column on the device (recognised from the
+                                               first cells of the manager's stream) instead of taking it from that stream cell by cell.
+                                               Opt-in: faster for tall partitions stopped by their goal and for batches, slower for many
+                                               small partitions one after the other (see runtime.cpp, AlignJob::setup) */
 #define MI355SW_F_NO_HOST_COUNTER 512       /* the kernel does not mirror its strip counter into host memory (measurements) */
 #define MI355SW_V_MESSAGES 1                /* one line per noteworthy event (overflow reruns, the diagonal seed, ...) */
 #define MI355SW_V_JOBS 2                    /* timing of every mi355sw_align_partition job */
