@@ -105,6 +105,8 @@ void Mi355Aligner::initialize() {
     if (params->getWaves() > 0) config.waves = params->getWaves();
     if (params->getStripRows() > 0) config.rows_per_lane = params->getStripRows() / 64;
     if (params->getNoDiagonalSeed()) config.flags |= MI355SW_F_NO_DIAGONAL_SEED;
+    config.flags |= params->getEngineFlags();
+    config.verbosity = params->getEngineVerbosity();
     if (params->getBlockColumns() > 0) {
         // the grid MASA-Core asks for (AlignerManager::dispatchScore -> BlocksFile::initialize(getGrid())) must be
         // known before the engine has picked anything: fixed strip height, one all three kernel families have

@@ -33,6 +33,12 @@
                            along the diagonal and start their pruning bound from the score found there;\n\
                            this option leaves that pass out (use it with --max-alignments > 1: a strong\n\
                            first bound prunes the weaker alignments away sooner).\n\
+--engine-flags=N        MI355SW_F_* switches of the engine (include/mi355sw.h), OR-ed together, decimal or 0x...:\n\
+                           32 two-phase best at every size, 1024 no pruning window, 2048 staircase seed,\n\
+                           4096 gap-initialised first columns made on the device, ... (the engine reads no\n\
+                           environment variable: this is where its switches come from).\n\
+--engine-verbosity=N    Diagnostics of the engine on stderr (MI355SW_V_*): 1 messages, 2 one line per\n\
+                           partition with its timing, 4 the seed's anchors and segments.\n\
 "
 
 #define ARG_GPU        0x1001
@@ -42,6 +48,8 @@
 #define ARG_BLOCK_COLUMNS 0x1005
 #define ARG_PRUNE_GLOBAL 0x1006
 #define ARG_NO_DIAGONAL_SEED 0x1007
+#define ARG_ENGINE_FLAGS 0x1008
+#define ARG_ENGINE_VERBOSITY 0x1009
 
 static struct option long_options[] = {
     {"gpu",        required_argument, 0, ARG_GPU},
@@ -51,10 +59,13 @@ static struct option long_options[] = {
     {"block-columns", required_argument, 0, ARG_BLOCK_COLUMNS},
     {"prune-global", no_argument, 0, ARG_PRUNE_GLOBAL},
     {"no-diagonal-seed", no_argument, 0, ARG_NO_DIAGONAL_SEED},
+    {"engine-flags", required_argument, 0, ARG_ENGINE_FLAGS},
+    {"engine-verbosity", required_argument, 0, ARG_ENGINE_VERBOSITY},
     {0, 0, 0, 0}
 };
 
-Mi355AlignerParameters::Mi355AlignerParameters() : gpu(MI355_DETECT_FASTEST_GPU), waves(0), stripRows(0), blockColumns(0), pruneGlobal(0), noDiagonalSeed(0) {}
+Mi355AlignerParameters::Mi355AlignerParameters() : gpu(MI355_DETECT_FASTEST_GPU), waves(0), stripRows(0), blockColumns(0), pruneGlobal(0), noDiagonalSeed(0),
+    engineFlags(0), engineVerbosity(0) {}
 Mi355AlignerParameters::~Mi355AlignerParameters() {}
 
 void Mi355AlignerParameters::printUsage() const {
@@ -166,6 +177,12 @@ int Mi355AlignerParameters::processArgument(int argc, char** argv) {
         break;
     case ARG_NO_DIAGONAL_SEED:
         noDiagonalSeed = 1;
+        break;
+    case ARG_ENGINE_FLAGS:              // the library reads no environment variable (ABI 7): its switches come from here
+        engineFlags = (int) strtol(optarg, NULL, 0);
+        break;
+    case ARG_ENGINE_VERBOSITY:
+        engineVerbosity = (int) strtol(optarg, NULL, 0);
         break;
     default:
         return ret;

@@ -24,12 +24,14 @@ public:
     int getBlockColumns() const { return blockColumns; }   /* --block-columns: width of the blocks whose scores are dispatched, 0 = none */
     int getPruneGlobal() const { return pruneGlobal; }     /* --prune-global: block pruning of partitions whose goal is the last cell */
     int getNoDiagonalSeed() const { return noDiagonalSeed; }   /* --no-diagonal-seed: MI355SW_F_NO_DIAGONAL_SEED */
+    int getEngineFlags() const { return engineFlags; }         /* --engine-flags=N: MI355SW_F_* bits OR-ed into mi355sw_config.flags (0x... accepted) */
+    int getEngineVerbosity() const { return engineVerbosity; } /* --engine-verbosity=N: MI355SW_V_* bits (1 = messages, 2 = one line per partition, ...) */
     static void printGPUDevices(FILE* file);          /* --list-gpus (X/cuda_util.cpp:191-230) */
     static int fastestGPU();                          /* X/cuda_util.cpp:238-287: largest CUs x clock */
     static int deviceWeights(int* weights, int max);  /* X/cuda_util.cpp:191-257: per-GPU weights, asked from a child process */
 
 private:
-    int gpu, waves, stripRows, blockColumns, pruneGlobal, noDiagonalSeed;
+    int gpu, waves, stripRows, blockColumns, pruneGlobal, noDiagonalSeed, engineFlags, engineVerbosity;
 };
 
 #endif

@@ -98,6 +98,11 @@ def test_extension_command_line_options(pkg, oracle):
     args = [a for a in case["args"] if not a.startswith("--block=")]
     res = _run(pkg, oracle, case["seq"], args + ["--gpu=0", "--blocks=64", "--strip-rows=512"])
     assert list(res["best"]) == case["best"]
+    # the engine's own switches (the library reads no environment variable: ABI 7) -- two-phase best tracking + no mixed strip
+    # heights + device-made gap columns, with one diagnostic line per partition
+    res = _run(pkg, oracle, case["seq"], args + ["--engine-flags=0x1060", "--engine-verbosity=2"])
+    assert list(res["best"]) == case["best"]
+    assert "[mi355sw] job" in res["log"]
     # the index range is checked when the engine starts (after any fork), not while the options are parsed
     s0, s1 = make_pair(pkg, case["seq"])
     tmp = tempfile.mkdtemp(prefix="masa_gpu99_")
