@@ -360,7 +360,11 @@ def main():
             # ports attached with hipDeviceEnablePeerAccess (mi355sw_port_attach, bands.InProcessChain) -- no hipIpc handle, no
             # second process.  Checked like the first: a 1 Mi-row chain must report what one band over all columns reports.
             al.portClose()
-            ipc_error = runner.p2p_error or "a neighbour rank failed"
+            # why: the rank that failed knows, the rank that writes the line may not -- collect every rank's reason (gloo side group)
+            whys = [None] * world
+            dist.all_gather_object(whys, runner.p2p_error, group=p2p_group)
+            whys = ["rank %d: %s" % (r, w) for r, w in enumerate(whys) if w]
+            ipc_error = "; ".join(whys[:3]) if whys else "the check failed with no reason given"
             flag = torch.zeros(1, dtype=torch.int32, device=coll_device)
             attach_error = None
             if rank == 0 and os.environ.get("MI355SW_BENCH_NO_ATTACH") != "1":

@@ -377,7 +377,15 @@ def _worker_verify(rank, world, port, m, n, fault, q):
         eng = OracleStreamEngine(oracle, s0, s1, seg=200)
         if rank == 1:
             eng.port_fault = fault
-        runner = BandRunner(eng, dist=dist, rank=rank, world=world, device=None, segment_rows=300, transport="p2p")
+        runner = BandRunner(eng, dist=dist, rank=rank, world=world, device=None, segment_rows=300, transport="p2p",
+                            prune_blocks=True)
+        seen_prune = []                 # the check compares boundary columns cell by cell: it must run UNPRUNED (bands.verify_p2p)
+        begin = eng.streamBegin
+
+        def spy(*a, **kw):
+            seen_prune.append(bool(kw.get("prune_blocks")))
+            return begin(*a, **kw)
+        eng.streamBegin = spy
 
         def all_min(v):
             t = torch.tensor([v], dtype=torch.int32)
@@ -385,6 +393,8 @@ def _worker_verify(rank, world, port, m, n, fault, q):
             return int(t.item())
         ok = all_min(1 if runner.probe_p2p(m) else 0) == 1
         verified = ok and runner.verify_p2p(m // 3, lim[rank], lim[rank + 1], all_min, budget_s=3.0)
+        assert seen_prune and not any(seen_prune) and runner.prune_blocks is True, (seen_prune, runner.prune_blocks)
+        eng.streamBegin = begin
         # the check's time budget travels as configuration (engine.configure, runner.stall_abort_s), not through os.environ
         env_restored = ("MI355SW_WAIT_S" not in os.environ and "MI355SW_BAND_STALL_S" not in os.environ and
                         eng._opts["wait_seconds"] == 0.0 and runner.stall_abort_s is None)
