@@ -3,6 +3,10 @@
 # repo root); replaces the per-round one-offs (r03_*.sh, r04_*.sh).  Everything lands under gpurun_out/TAG/.
 #   new:FILES      pytest -m gpu -x of the listed test files (comma separated, without tests/ and .py)
 #   suite          the whole GPU suite (pytest tests -m gpu), then __graft_entry__.smoke()
+#   fastsuite[:N]  the GPU suite under pytest-xdist (N workers, default 6, one test FILE per worker at a time: module fixtures stay whole),
+#                  then the tests that failed once more ALONE -- the box has 256 host cores and the suite's time is the oracle's
+#                  and Python's, not the GPU's: 140 s instead of 500 s (profiles/r05_gpu_suite_xdist_rehearsal.log); tests that
+#                  bound a run's TIME may fail next to five other processes on the GPU, hence the second, serial pass
 #   bench          python3 bench.py (the driver's N = 1 command) -> bench.json
 #   selflaunch:N   MI355SW_BENCH_REHEARSAL=1 python3 bench.py --gpus N --size 300000  (bench.py starts its own ranks; all on cuda:0)
 #   rehearse       the N > 1 path of bench.py on the one GPU through every transport and recurrence (self-launched)
@@ -25,6 +29,14 @@ for step in "$@"; do
     suite)
         timeout 2400 python3 -m pytest tests -q -m gpu > $out/suite.log 2>&1; rc=$?
         tail -8 $out/suite.log
+        timeout 300 python3 -c "import __graft_entry__ as g; g.smoke()" > $out/smoke.log 2>&1; echo "smoke rc=$?"; tail -2 $out/smoke.log ;;
+    fastsuite)
+        timeout 1200 python3 -m pytest tests -q -m gpu -n ${arg:-6} --dist loadfile > $out/fastsuite.log 2>&1; rc=$?
+        tail -5 $out/fastsuite.log
+        if [ $rc -ne 0 ]; then
+            timeout 1200 python3 -m pytest tests -q -m gpu --last-failed > $out/fastsuite_failed_alone.log 2>&1; rc=$?
+            echo "-- the failed ones alone:"; tail -5 $out/fastsuite_failed_alone.log
+        fi
         timeout 300 python3 -c "import __graft_entry__ as g; g.smoke()" > $out/smoke.log 2>&1; echo "smoke rc=$?"; tail -2 $out/smoke.log ;;
     bench)
         timeout 1700 python3 bench.py > $out/bench.json 2> $out/bench.err; rc=$?
