@@ -438,7 +438,8 @@ class MI355Aligner:
         self._check(self._lib.mi355sw_set_rows_per_lane(self._h, int(rows_per_lane)), "setRowsPerLane")
         self._rows_per_lane = int(rows_per_lane)
         self._opts["rows_per_lane"] = int(rows_per_lane)
-        self._cfg_key = self._config_key(self._make_config())
+        # (the library has this one value already; anything else that changed meanwhile is still to be handed over by _sync_config)
+        self._cfg_key = (int(rows_per_lane),) + tuple(self._cfg_key[1:])
 
     def getRowsPerLane(self):
         return getattr(self, "_rows_per_lane", None)
@@ -620,9 +621,13 @@ class MI355Aligner:
         out, n, st = C.c_void_p(), C.c_int32(), Stage4Stats()
         self._check(self._lib.mi355sw_stage4(self._h, cp.ctypes.data, len(cp), max_partition_size, C.byref(out), C.byref(n),
                                              C.byref(st)), "stage4")
-        buf = (C.c_int32 * (n.value * 4)).from_address(out.value)
-        res = np.frombuffer(buf, dtype=np.int32).reshape(n.value, 4).copy()
-        self._lib.mi355sw_free(out)
+        if n.value > 0 and out.value:
+            buf = (C.c_int32 * (n.value * 4)).from_address(out.value)
+            res = np.frombuffer(buf, dtype=np.int32).reshape(n.value, 4).copy()
+        else:
+            res = np.empty((0, 4), dtype=np.int32)
+        if out.value:
+            self._lib.mi355sw_free(out)
         stats = {k: getattr(st, k) for k, _ in Stage4Stats._fields_}
         return (res if as_array else [tuple(r) for r in res.tolist()]), stats
 
