@@ -141,3 +141,17 @@ def test_chain_seed_bound_only_where_the_seed_applies(pkg, monkeypatch):
     monkeypatch.setenv("MI355SW_NO_DIAGONAL_SEED", "1")
     assert bands.chain_seed_bound(e, big, big, pkg.SMITH_WATERMAN, Z, Z) is None
     assert len(e.asked) == 2
+
+
+def test_gpu_call_scripts_parse_and_python_tools_compile():
+    """the scripts a GPU call runs are not exercised by any CPU test: a syntax error in one of them costs a box (minutes of the
+    round's GPU budget) to find.  bash -n for the shell ones, py_compile for the Python ones."""
+    import glob
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for sh in sorted(glob.glob(os.path.join(root, "tools", "*.sh")) + glob.glob(os.path.join(root, "oracle", "*.sh"))):
+        r = subprocess.run(["bash", "-n", sh], capture_output=True, text=True)
+        assert r.returncode == 0, (sh, r.stderr)
+    for py in sorted(glob.glob(os.path.join(root, "tools", "*.py")) + [os.path.join(root, "bench.py"), os.path.join(root, "__graft_entry__.py")]):
+        compile(open(py, "rb").read(), py, "exec")
