@@ -48,6 +48,26 @@ def _u4c(v):
     return bytes([0x80 | g for g in groups[k:4]] + [groups[4]])
 
 
+def _gaps_bytes(gaps):
+    """the gap list of one sequence as the file holds it: (position - previous position, length) per gap, both
+    fwrite_uint4_compressed -- _u4c over the whole list at once (a chromosome pair has 10^5..10^6 gaps)"""
+    import numpy as np
+    if len(gaps) == 0:
+        return b""
+    g = np.asarray(gaps, dtype=np.int64).reshape(-1, 2)
+    v = np.empty((len(g), 2), dtype=np.int64)
+    v[:, 0] = np.diff(g[:, 0], prepend=0)
+    v[:, 1] = g[:, 1]
+    v = v.reshape(-1) & 0xFFFFFFFF
+    groups = np.stack([(v >> 28) & 0xF, (v >> 21) & 0x7F, (v >> 14) & 0x7F, (v >> 7) & 0x7F, v & 0x7F], axis=1).astype(np.uint8)
+    nz = groups[:, :4] != 0
+    first = np.where(nz.any(axis=1), nz.argmax(axis=1), 4)            # leading zero groups are not written
+    keep = np.arange(5)[None, :] >= first[:, None]
+    keep[:, 4] = True
+    groups[:, :4] |= 0x80
+    return groups[keep].tobytes()
+
+
 def _flags(seq):
     """fwrite_flags (:402-415); the trim range is the normalised one (open ends filled in: 1 .. size)"""
     mod = seq.modifiers
@@ -73,10 +93,7 @@ def dumps(alignment, seq0, seq1, match=1, mismatch=-3, gap_open=3, gap_ext=2):
             b"\x05"]
     for k in range(2):
         out += [_i4(alignment.start[k]), _i4(alignment.end[k]), _i4(len(alignment.gaps[k]))]
-        last = 0
-        for pos, length in alignment.gaps[k]:
-            out += [_u4c(pos - last), _u4c(length)]
-            last = pos
+        out.append(_gaps_bytes(alignment.gaps[k]))
     out.append(b"\x00")
     return b"".join(out)
 

@@ -103,7 +103,13 @@ def _traceback(aligner, seq0, seq1, d0, d1, work, ident, alignment_start, sra_li
             cp4, st4 = aligner.stage4(r3["crosspoints"], max_partition_size)
     finally:
         aligner.unsetSequences()
-    save_array(crosspoint_file(work, 4, ident), cp4)          # (millions of points at sizes like C3: no object per point)
+    # crosspoint_04: millions of points at sizes like C3 (130 MB of text, seconds of formatting).  Nothing in this run reads the
+    # file back -- stage 5 takes the array -- so it is written by the areas' file thread while stages 5 and 6 run in the library
+    # (their calls release the interpreter); in place when align() returns, like every queued file (sra.async_files)
+    if isinstance(cp4, np.ndarray):
+        sra_mod.queue_file_operation(_traceback, save_array, crosspoint_file(work, 4, ident), cp4)
+    else:
+        save_array(crosspoint_file(work, 4, ident), cp4)
     clock(4, t)
     t = time.time()
     al = stage56.stage5(seq0, seq1, cp4)

@@ -163,6 +163,13 @@ def drain():
     _files.drain()
 
 
+def queue_file_operation(owner, fn, *args, nbytes=0):
+    """fn(*args) as one more file operation of the running stages: carried out by the file thread, after everything asked for
+    before it, inside async_files(); at once otherwise.  For files that nothing in the same run reads back (the pipeline's
+    crosspoint_04: 130 MB of text at C3's size, formatted while stages 5 and 6 run in the library)."""
+    _files.submit(owner, fn, *args, nbytes=nbytes)
+
+
 @contextlib.contextmanager
 def async_files():
     """while the block runs, the areas' file operations are queued (see _FileQueue); all carried out when it ends"""

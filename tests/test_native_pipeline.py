@@ -628,3 +628,37 @@ def test_manager_goal_matching(pkg, oracle):
     mg.alignPartition(pkg.Partition(0, 0, 40, 40), START_TYPE_MATCH)
     assert mg.isFoundCrosspoint() and mg.getNextCrosspoint() == (40, 40, 0, 0)
     mg.unsetSequences()
+
+
+def test_crosspoint_04_written_by_the_file_thread_is_the_same_file(pkg, oracle, tmp_path):
+    """an aligner whose stage4 hands back an ARRAY (the engine's form, millions of points at C3's size) has crosspoint_04 written
+    by the areas' file thread while stages 5 and 6 run (pipeline._traceback): in place when align() returns, the same bytes as
+    the list form written inline, and the operation really went through the queue"""
+    from masa_cudalign_amd import pipeline, sra
+    from masa_cudalign_amd.crosspoints import crosspoint_file
+    from oracle.aligner_double import SerialBlockAligner
+    case = [c for c in FULL if c["name"] == "full_pipeline_3000x2700"][0]
+    s0, s1 = make_pair(pkg, case["seq"])
+    q0, q1 = _fasta(pkg, s0, s1)
+
+    class ArrayForm(SerialBlockAligner):
+        def stage4(self, crosspoints, max_partition_size=16, as_array=False):
+            out, st = SerialBlockAligner.stage4(self, crosspoints, max_partition_size)
+            return (np.asarray(out, dtype=np.int32).reshape(-1, 4) if as_array else out), st
+
+    queued = []
+    submit = sra._files.submit
+
+    def spy(owner, fn, *a, **kw):
+        queued.append((fn.__name__, sra._files._enabled()))
+        return submit(owner, fn, *a, **kw)
+    sra._files.submit = spy
+    try:
+        work = str(tmp_path / "array")
+        out = pipeline.align(ArrayForm(128, 128), q0, q1, work, sra_limit=_limit(case["args"]), block_pruning=False)
+    finally:
+        sra._files.submit = submit
+    assert ("save_array", True) in queued
+    assert not sra._files.has_pending()
+    assert hashlib.sha256(open(crosspoint_file(work, 4), "rb").read()).hexdigest() == case["crosspoints_4"]["file_sha256"]
+    assert hashlib.sha256(out["text"]).hexdigest() == case["alignment_txt_sha256"]
