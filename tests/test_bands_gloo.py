@@ -161,6 +161,9 @@ class OracleStreamEngine:
             self._segment_done(r1)
 
     def _segment_done(self, r1):
+        if getattr(self, "segment_delay", 0):            # (tests whose point is what arrives WHILE a band computes)
+            import time
+            time.sleep(self.segment_delay)
         if self.sp_k and (r1 // self.seg) % self.sp_k == 0 and r1 % self.seg == 0 and r1 < self.m:
             self.sp_rows[r1] = self.row[1:].copy()
         self._relay()
@@ -504,6 +507,10 @@ def _worker_prune(rank, world, port, m, n, transport, q):
             if mode == "pruned_alone":
                 os.environ["MI355SW_NO_SHARED_BEST"] = "1"
             eng = OracleStreamEngine(oracle, s0, s1, seg=256)   # strip heights are multiples of 256, as the engine's
+            # the stand-in sweeps a band in a millisecond or two, the host transport's side thread exchanges the chain's best
+            # every 2 ms: whether a hint arrives before a band is through would be the scheduler's choice (seen once in a
+            # full-suite run on a loaded machine).  A real band takes seconds; 10 ms per row segment keeps the order of events.
+            eng.segment_delay = 0.01
             runner = BandRunner(eng, dist=dist, rank=rank, world=world, device=None, segment_rows=300, transport=transport,
                                 prune_blocks=(mode != "plain"))
             if transport == "p2p":
