@@ -662,3 +662,41 @@ def test_crosspoint_04_written_by_the_file_thread_is_the_same_file(pkg, oracle, 
     assert not sra._files.has_pending()
     assert hashlib.sha256(open(crosspoint_file(work, 4), "rb").read()).hexdigest() == case["crosspoints_4"]["file_sha256"]
     assert hashlib.sha256(out["text"]).hexdigest() == case["alignment_txt_sha256"]
+
+
+def test_stage3_walks_handed_over_together_give_the_same_files(pkg, oracle, tmp_path):
+    """stage 3 hands the pending sweeps of all its walks to the aligner in ONE call when the aligner offers alignPartitions
+    (MI355Aligner: one kernel launch) and one by one otherwise (stage3._run_walks).  The CPU double with an alignPartitions
+    that serves its partitions in turn: the batched branch runs here too -- same crosspoint files and the same special rows as
+    the one-by-one branch, over two rounds of stage 3, and the batches really held several partitions."""
+    from oracle.aligner_double import SerialBlockAligner
+    from masa_cudalign_amd.stage1 import stage1
+    from masa_cudalign_amd.stage2 import stage2
+    from masa_cudalign_amd.stage3 import stage3
+    batches = []
+
+    class Batched(SerialBlockAligner):
+        def alignPartitions(self, partitions, managers):
+            assert len(partitions) == len(managers) and len({id(g) for g in managers}) == len(managers)
+            batches.append(len(partitions))
+            for part, mgr in zip(partitions, managers):
+                self.alignPartition(part, mgr)
+
+    s0, s1 = pkg.seqgen.related_pair(27648, 27648, cfg=7)
+    limit = 663552
+    out = {}
+    for name, cls in (("one_by_one", SerialBlockAligner), ("batched", Batched)):
+        work = str(tmp_path / name)
+        al = cls(256, 256)
+        stage1(al, s0, s1, work, sra_limit=limit, block_pruning=False)
+        stage2(al, s0, s1, work, sra_limit=limit)
+        out[name] = (work, stage3(al, s0, s1, work, sra_limit=limit))
+    assert len(out["batched"][1]["rounds"]) == 2 and max(batches) > 1
+    assert out["batched"][1]["crosspoints"] == out["one_by_one"][1]["crosspoints"]
+    assert out["batched"][1]["rounds"] == out["one_by_one"][1]["rounds"]
+    a, b = out["one_by_one"][0], out["batched"][0]
+    for f in sorted(os.listdir(os.path.join(a, "crosspoints"))):
+        assert filecmp.cmp(os.path.join(a, "crosspoints", f), os.path.join(b, "crosspoints", f), shallow=False), f
+    p = subprocess.run(["diff", "-rq", os.path.join(a, "special_rows"), os.path.join(b, "special_rows")],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    assert p.returncode == 0, p.stdout.decode()[:2000]
