@@ -338,6 +338,10 @@ class SpecialRowsPartition:
         self.ram_proportion, self.disk_proportion = 0, 1
         self.ram_count = self.disk_count = 0
         self.rows = []                 # ids (i - i0) of complete rows, ascending (the first row, id 0, is implicit)
+        # id -> (largest H of the row, its cell index): kept while the rows are written when stage 2 is going to guess its
+        # crosspoints from them (stage2.py, MI355SW_STAGE2_SPECULATE); lives with the object, i.e. for the stages of one process
+        self.track_peaks = bool(os.environ.get("MI355SW_STAGE2_SPECULATE"))
+        self.peaks = {}
         self.reading = None            # SpecialRowReader handed out last
         self._reading_idx = 0
         self.largest_interval = 0
@@ -516,6 +520,21 @@ class SpecialRowsPartition:
         _files.wait(self)
         return np.fromfile(self.row_filename(i), dtype=np.int32).reshape(-1, 2)
 
+    def row_peak(self, rid, max_index):
+        """(H, cell index) of the largest H among cells 1..max_index of complete row `rid` (cell c = DP column j0 + c; the first
+        of several equal ones) -- from the record kept while the row was written when that lies in range, from the row itself
+        otherwise; None for the first row and for an empty range"""
+        if rid == 0 or max_index < 1:
+            return None
+        p = self.peaks.get(rid)
+        if p is not None and 1 <= p[1] <= max_index:
+            return p
+        cells = self.read_row(self.i0 + rid)[1:max_index + 1]
+        if len(cells) == 0:
+            return None
+        k = int(np.argmax(cells[:, 0]))
+        return int(cells[k, 0]), k + 1
+
     def last_disk_row_id(self):
         """absolute DP row of the last complete row ON DISK (what a later process can continue from)"""
         disk = [r for r in self.rows if r not in self._ram]
@@ -540,6 +559,11 @@ class SpecialRowsPartition:
         if row is None:
             row = self._open[rid] = (_OpenRow(self.path, rid, self.width_cells, self) if self._next_row_on_disk()
                                      else _OpenRamRow(rid, self.width_cells))
+        if self.track_peaks and len(cells):
+            h = np.asarray(cells)[:, 0]
+            k = int(np.argmax(h))
+            if rid not in self.peaks or int(h[k]) > self.peaks[rid][0]:
+                self.peaks[rid] = (int(h[k]), row.offset + k)
         row.write(cells)
         if row.offset >= self.width_cells:
             if isinstance(row, _OpenRamRow):
@@ -626,6 +650,17 @@ class SpecialRowsArea:
             self.partitions.pop(old, None)
             self.partitions[new] = p
         self.rows += p.rows_count()
+
+    def discard_partition(self, p):
+        """a partition nobody is going to read (stage 2's sweep from a crosspoint guess that turned out wrong): its rows, its
+        directory and its entry go away -- no counterpart in the reference, which never sweeps on a guess"""
+        p.close()
+        p._ram = {}
+        if self.persistent and p.path:
+            import shutil
+            if self.partitions.get(p.path) is p:
+                del self.partitions[p.path]
+            _files.submit(p, shutil.rmtree, p.path, True)
 
     def rows_count(self):
         """(:97-103)"""

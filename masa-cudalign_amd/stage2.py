@@ -13,6 +13,7 @@ alignment the walk ends inside a partition, at the cell whose reverse value alon
 
 Everything is written in the reference's formats (crosspoints.py, sra.py): `crosspoint_02.NN` (in this stage's
 reversed coordinates, like MASA-Core's) and `special_rows/stage.02.NN/`."""
+import os
 import time
 
 import numpy as np
@@ -83,14 +84,148 @@ def find_next_crosspoint(mgr, area, c0, c1, alignment_start, must_find=True, goa
     return conclude_next_crosspoint(mgr, area, part, c0, c1, must_find)
 
 
+class _GuessManager(AlignerManager):
+    """The manager of a sweep that starts from a GUESSED crosspoint (_Speculation).  A wrong guess shows as a border sum above
+    its goal -- "backtrace lost" for a real walk, just a wrong guess here -- or as a goal that never turns up: the sweep is
+    stopped (mustContinue) instead of raising, at the latest `row_cap` rows down its last column, and says so in `gave_up`."""
+
+    @classmethod
+    def of(cls, mgr, row_cap):
+        c = cls(mgr.aligner)
+        c.recurrence, c.block_pruning, c.special_row_interval = mgr.recurrence, mgr.block_pruning, mgr.special_row_interval
+        c.seq0_offset, c.seq1_offset = mgr.seq0_offset, mgr.seq1_offset
+        c.row_cap, c.gave_up = int(row_cap), None
+        return c
+
+    def _find_goal_cell(self, buf, length, reader):
+        try:
+            return AlignerManager._find_goal_cell(self, buf, length, reader)
+        except BacktraceLost as e:
+            self.gave_up = str(e)
+            self.active = False
+            return None
+
+    def dispatchColumn(self, j, buf, length):
+        AlignerManager.dispatchColumn(self, j, buf, length)
+        if self.active and not self.found and self.last_column_pos > self.row_cap:
+            self.gave_up = "no goal within %d rows" % self.row_cap
+            self.active = False
+
+
+class _Speculation:
+    """Stage 2's walk is a chain: the sweep towards special row k+1 starts at the crosspoint the sweep towards row k found,
+    so the sweeps run one after the other, each a few hundred thousand rows of latency on a GPU that could take dozens
+    side by side (C3: 68 sweeps, 0.2 s each).  But where the crosspoints WILL be can be guessed before any of them ran:
+    the optimal alignment crosses a special row of stage 1 where that row's H is largest (the prefix of an optimal
+    alignment is the best alignment that ends there), as an aligned pair, with that H as its score.  So: one sweep from the
+    real crosspoint and one from the guess on every row further up, all handed to the aligner together
+    (MI355Aligner.alignPartitions: one kernel launch); then the walk takes them in order -- a sweep counts only if it started
+    at exactly the crosspoint (cell, score AND type) the sweep before it found.  From such a start it is the sweep the
+    plain walk would have made: same borders, same goal, same special rows saved, same hit.  A guess that is off (the path
+    crosses the row inside a gap, or one of several co-optimal paths is met first) costs its sweep, which is thrown away
+    (SpecialRowsArea.discard_partition), and the walk makes that one step the plain way.  The files of the stage do not
+    change.  No counterpart in the reference (its stage 2 is the plain chain, sw_stage2.cpp:387-441).
+
+    Opt-in (stage2(speculate=True) or MI355SW_STAGE2_SPECULATE=1); the row maxima are recorded by stage 1 while it writes
+    the rows when the variable is set for the whole run (SpecialRowsPartition.peaks), read back from the rows otherwise."""
+
+    def __init__(self, mgr, area, part1, cp, col_reader, len_v, len_h, alignment_start):
+        self.area = area
+        self.sweeps = {}
+        self.made = self.accepted = self.discarded = 0
+        ids = [0] + part1.rows
+
+        def target(i_abs, idx):                         # SpecialRowsPartition.next_special_row's choice, without its state
+            while idx >= 0:
+                dist = (i_abs - part1.i0) - ids[idx]
+                if idx == 0:
+                    return 0 if dist > 0 else None
+                if dist > MIN_ROW_DISTANCE:
+                    return idx
+                idx -= 1
+            return None
+
+        chain = []                                       # (crosspoint the sweep starts from, index of its row, guessed?)
+        c0, idx, guess = cp.copy(), part1._reading_idx, False
+        while True:
+            c0_r = c0.reverse(len_v, len_h)
+            if (alignment_start == AT_ANYWHERE and c0.score <= 0) or c0_r.i <= part1.i0 or c0_r.j <= part1.j0:
+                break
+            t = target(c0_r.i, idx)
+            if t is None:
+                break
+            chain.append((c0, t, guess))
+            peak = part1.row_peak(ids[t], c0_r.j - part1.j0)
+            if peak is None:
+                break
+            c0 = Crosspoint(part1.i0 + ids[t], part1.j0 + peak[1], peak[0], TYPE_MATCH).reverse(len_h, len_v)
+            idx, guess = t, True
+        if len(chain) < 2:
+            return
+        jobs = []
+        try:
+            for c0, t, guess in chain:
+                c0_r = c0.reverse(len_v, len_h)
+                c1 = Crosspoint(len_v - part1.j0, len_h - (part1.i0 + ids[t]))
+                m = _GuessManager.of(mgr, 2 * (c1.j - c0.j) + 4096) if guess else mgr.clone()
+                row = sra_mod.SpecialRowReader(part1, ids[t])
+                row.seek(abs(c0_r.j - part1.j0) + 1)
+                m.setLastColumnReader(row)
+                if col_reader is not None:
+                    col = ReversedCellsReader(col_reader)
+                    col.seek(c0_r.i - part1.i0 + 1)
+                    m.setLastRowReader(col)
+                part, adj = prepare_next_crosspoint(m, area, c0, c1, alignment_start)
+                sw = dict(mgr=m, part=part, c0=c0, c1=c1, guess=guess)
+                self.sweeps[(c0.astuple(), c1.astuple())] = sw
+                if adj is not None:
+                    jobs.append((m, adj))
+            self.made = len(self.sweeps)
+            if len(jobs) > 1 and hasattr(mgr.aligner, "alignPartitions"):
+                mgr.aligner.alignPartitions([a for _, a in jobs], [m for m, _ in jobs])
+            else:
+                for m, a in jobs:
+                    mgr.aligner.alignPartition(a, m)
+        except BaseException:
+            self.discard_rest()
+            raise
+
+    def take(self, cp, c1):
+        """the finished sweep cp -> c1, or None when the walk has to make this step itself"""
+        sw = self.sweeps.pop((cp.astuple(), c1.astuple()), None)
+        if sw is not None and sw["guess"] and (sw["mgr"].gave_up or not sw["mgr"].isFoundCrosspoint()):
+            self._discard(sw)                        # (a right start, but the goal lay beyond the cap: the plain way)
+            sw = None
+        if sw is None:
+            # a sweep from the same CELL with another score or type would leave its directory where the walk's own goes
+            for key in [k for k, o in self.sweeps.items() if (o["c0"].i, o["c0"].j, o["c1"].i, o["c1"].j) == (cp.i, cp.j, c1.i, c1.j)]:
+                self._discard(self.sweeps.pop(key))
+            return None
+        self.accepted += 1
+        return sw
+
+    def _discard(self, sw):
+        self.area.discard_partition(sw["part"])
+        self.discarded += 1
+
+    def discard_rest(self):
+        for sw in self.sweeps.values():
+            self._discard(sw)
+        self.sweeps = {}
+
+
 @sra_mod.with_async_files
 def stage2(aligner, seq0, seq1, work, alignment_start=AT_ANYWHERE, sra_limit=0, ident=0, bounds=None, ram_limit=0,
-           areas=None):
+           areas=None, speculate=None):
     """Runs stage 2 for alignment `ident` of work directory `work` (stage 1 must have left crosspoint_01.NN and,
     with sra_limit > 0, its special rows there).  seq0 / seq1: the whole sequences; `bounds` = (i0, j0, i1, j1) the
     part --trim selected for stage 1 (only its origin matters here: where a global alignment must begin).  Returns {"crosspoints": [(type, i, j, score), ...] as written to
-    crosspoint_02.NN, "end": the last crosspoint in ORIGINAL coordinates, "partitions", "seconds"}."""
+    crosspoint_02.NN, "end": the last crosspoint in ORIGINAL coordinates, "partitions", "seconds"}.
+    speculate: sweeps from guessed crosspoints side by side (_Speculation); None = MI355SW_STAGE2_SPECULATE."""
     t_start = time.time()
+    if speculate is None:
+        speculate = bool(os.environ.get("MI355SW_STAGE2_SPECULATE"))
+    guessed = {"sweeps": 0, "accepted": 0, "discarded": 0}
     s0, s1 = _as_u8(seq0), _as_u8(seq1)
     m, n = len(s0), len(s1)
     seq_v = np.ascontiguousarray(s1[::-1])               # sw_stage2.cpp:258-276: reverse = 1
@@ -139,7 +274,10 @@ def stage2(aligner, seq0, seq1, work, alignment_start=AT_ANYWHERE, sra_limit=0, 
             col_reader, row_reader = part1.first_column_reader, part1.first_row_reader
             corner = Crosspoint(part1.i0, part1.j0).reverse(len_h, len_v)
             mgr.setSequences(seq_v, seq_h, cp.i, cp.j, corner.i, corner.j)
+            spec = None
             try:
+                if speculate:
+                    spec = _Speculation(mgr, area2, part1, cp, col_reader, len_v, len_h, alignment_start)
                 while True:
                     cp_r = cp.reverse(len_v, len_h)
                     if alignment_start == AT_ANYWHERE and cp.score <= 0:
@@ -156,12 +294,20 @@ def stage2(aligner, seq0, seq1, work, alignment_start=AT_ANYWHERE, sra_limit=0, 
                     else:
                         mgr.setLastRowReader(None)
                     c1 = Crosspoint(len_v - part1.j0, len_h - part1.get_reading_row())
-                    cp = find_next_crosspoint(mgr, area2, cp, c1, alignment_start)
+                    done = spec.take(cp, c1) if spec is not None else None
+                    if done is not None:
+                        cp = conclude_next_crosspoint(done["mgr"], area2, done["part"], cp, c1)
+                    else:
+                        cp = find_next_crosspoint(mgr, area2, cp, c1, alignment_start)
                     partitions += 1
                     out.write(cp)
                     if cp.type != TYPE_MATCH:
                         cp.score += GAP_OPEN
             finally:
+                if spec is not None:
+                    spec.discard_rest()
+                    for k, v in (("sweeps", spec.made), ("accepted", spec.accepted), ("discarded", spec.discarded)):
+                        guessed[k] += v
                 mgr.unsetSequences()
             cp_r = cp.reverse(len_v, len_h)
             part1 = area1.open_partition_at(cp_r.i, cp_r.j)
@@ -179,4 +325,5 @@ def stage2(aligner, seq0, seq1, work, alignment_start=AT_ANYWHERE, sra_limit=0, 
         out.close()
         if short_strips:
             aligner.setRowsPerLane(0)
-    return {"crosspoints": out.tuples(), "end": cp_r.astuple(), "partitions": partitions, "seconds": time.time() - t_start}
+    return {"crosspoints": out.tuples(), "end": cp_r.astuple(), "partitions": partitions, "seconds": time.time() - t_start,
+            "speculation": guessed if speculate else None}

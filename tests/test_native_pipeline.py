@@ -700,3 +700,84 @@ def test_stage3_walks_handed_over_together_give_the_same_files(pkg, oracle, tmp_
     p = subprocess.run(["diff", "-rq", os.path.join(a, "special_rows"), os.path.join(b, "special_rows")],
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     assert p.returncode == 0, p.stdout.decode()[:2000]
+
+
+SPEC = [
+    ("related", lambda pkg: pkg.seqgen.related_pair(27648, 27648, cfg=7), 256, 256, 663552, "**"),
+    ("many_indels", lambda pkg: pkg.seqgen.related_pair(12000, 12000, cfg=21, p_indel=0.02, indel_mean=6.0), 128, 128, 300 * 1024, "**"),
+    ("wide_long_indels", lambda pkg: pkg.seqgen.related_pair(9000, 14000, cfg=22, p_indel=0.01, indel_mean=20.0), 256, 128, 200 * 1024, "**"),
+    ("gap_rich", lambda pkg: _gap_rich(), 128, 128, 100 * 1024, "**"),
+    ("global", lambda pkg: pkg.seqgen.related_pair(6000, 6100, cfg=23, inversion=0.0), 128, 128, 150 * 1024, "++"),
+    ("contained_semiglobal_21", _contained, 128, 128, 150 * 1024, "21"),
+    ("unrelated", lambda pkg: pkg.seqgen.unrelated_pair(5000, 5000, cfg=3), 128, 128, 100 * 1024, "**"),
+]
+
+
+def _same_tree(a, b, sub):
+    p = subprocess.run(["diff", "-rq", os.path.join(a, sub), os.path.join(b, sub)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    assert p.returncode == 0, p.stdout.decode()[:2000]
+
+
+@pytest.mark.parametrize("name,pair,bh,bw,limit,edges", SPEC, ids=[x[0] for x in SPEC])
+def test_stage2_from_guessed_crosspoints_leaves_the_same_files(name, pair, bh, bw, limit, edges, pkg, oracle, tmp_path, monkeypatch):
+    """stage 2 with its sweeps started side by side from GUESSED crosspoints (stage2._Speculation: the row maxima of stage 1's
+    special rows) against the plain chain: the same crosspoint_02, the same special rows for stage 3 (and so the same stage 3),
+    whether the aligner takes the sweeps together (alignPartitions) or one by one; most guesses are right on related pairs;
+    and with every guess made wrong on purpose the walk falls back to the plain step, throws the sweeps away and still
+    leaves the same files."""
+    from oracle.aligner_double import SerialBlockAligner
+    from masa_cudalign_amd.stage1 import stage1
+    from masa_cudalign_amd.stage2 import stage2
+    from masa_cudalign_amd.stage3 import stage3
+    from masa_cudalign_amd import sra
+    edge = {"*": pkg.AT_ANYWHERE, "1": pkg.AT_SEQUENCE_1, "2": pkg.AT_SEQUENCE_2, "3": pkg.AT_SEQUENCE_1_OR_2,
+            "+": pkg.AT_SEQUENCE_1_AND_2}
+    batches = []
+
+    class Batched(SerialBlockAligner):
+        def alignPartitions(self, partitions, managers):
+            batches.append(len(partitions))
+            for part, mgr in zip(partitions, managers):
+                self.alignPartition(part, mgr)
+
+    s0, s1 = pair(pkg)
+    runs = {}
+    for mode in ("plain", "guessed", "guessed_batched", "recorded_peaks", "all_guesses_wrong"):
+        work = str(tmp_path / mode)
+        al = (Batched if mode == "guessed_batched" else SerialBlockAligner)(bh, bw)
+        areas = {}
+        if mode == "recorded_peaks":                 # the variable set for the whole run: stage 1 records the maxima as it writes
+            monkeypatch.setenv("MI355SW_STAGE2_SPECULATE", "1")
+        if mode == "all_guesses_wrong":
+            real = sra.SpecialRowsPartition.row_peak
+
+            def off_by_some(self, rid, max_index):
+                p = real(self, rid, max_index)
+                return None if p is None else (p[0], max(1, p[1] - 7))
+            monkeypatch.setattr(sra.SpecialRowsPartition, "row_peak", off_by_some)
+        stage1(al, s0, s1, work, alignment_start=edge[edges[0]], alignment_end=edge[edges[1]], sra_limit=limit, block_pruning=False,
+               areas=areas)
+        r2 = stage2(al, s0, s1, work, alignment_start=edge[edges[0]], sra_limit=limit, areas=areas,
+                    speculate=None if mode in ("plain", "recorded_peaks") else True)
+        r3 = stage3(al, s0, s1, work, sra_limit=limit, areas=areas)
+        monkeypatch.delenv("MI355SW_STAGE2_SPECULATE", raising=False)
+        monkeypatch.undo()
+        runs[mode] = (work, r2, r3)
+    plain = runs["plain"]
+    assert plain[1]["speculation"] is None
+    for mode in ("guessed", "guessed_batched", "recorded_peaks", "all_guesses_wrong"):
+        work, r2, r3 = runs[mode]
+        assert r2["crosspoints"] == plain[1]["crosspoints"] and r2["partitions"] == plain[1]["partitions"], mode
+        assert r3["crosspoints"] == plain[2]["crosspoints"], mode
+        _same_tree(plain[0], work, "crosspoints")
+        _same_tree(plain[0], work, os.path.join("special_rows", "stage.02.00"))
+        sp = r2["speculation"]
+        assert sp["accepted"] + sp["discarded"] == sp["sweeps"], (mode, sp)
+        if mode == "all_guesses_wrong":
+            assert sp["accepted"] <= 1 + (sp["sweeps"] > 0), (mode, sp)     # only sweeps from real crosspoints count
+    sp = runs["guessed"][1]["speculation"]
+    if name in ("related", "many_indels", "global"):
+        assert sp["sweeps"] >= 3 and sp["accepted"] >= sp["sweeps"] - 2, sp  # nearly every guess was the crosspoint
+    if runs["guessed_batched"][1]["speculation"]["sweeps"] > 1:
+        assert max(batches) > 1
+    assert runs["recorded_peaks"][1]["speculation"] == runs["guessed"][1]["speculation"]
