@@ -188,6 +188,48 @@ def self_launch(argv, gpus):
     return rc
 
 
+def launch_check_backend(world, devices_visible, forced=None):
+    """which torch.distributed backend --launch-check joins: the real run's "nccl" (RCCL) as soon as there is one device per
+    rank, gloo otherwise; MI355SW_LAUNCH_CHECK_BACKEND forces one"""
+    if forced in ("nccl", "gloo"):
+        return forced
+    return "nccl" if (world > 1 and devices_visible >= world) else "gloo"
+
+
+# BASELINE.json's multi-GPU configurations as one-shot extras of the `--gpus N` line (like c3_full at N = 1): run ONCE after the
+# timed weak-scaling steps, on all ranks, through the same band driver and transport the headline settled on.
+#   N = 4: C4 -- 59 M x 64 M unrelated, local SW, 4 column bands
+#   N = 8: C5 -- 249 M x 228 M related, global NW, block pruning on (the chain's bound starts from the seed of the whole matrix)
+#   N = 2: the first two bands of C4 as a matrix of their own (59 M x 32 M)
+# `expect`: what a one-GPU run of the same pair recorded (profiles/), 1-based DP cell.  MI355SW_BENCH_REHEARSAL=1 runs them at
+# 1/16 of the linear size (a one-GPU box; nothing recorded to compare with: the chain must equal one band over all columns).
+FULL_CONFIGS = {
+    2: dict(key="c4_half", m=59000000, n=32000000, related=False, nw=False, cfg=5, est_s=200,
+            workload="BASELINE config 4's first two bands as a matrix of their own: %dx%d unrelated random ACGT, local SW, 2 column bands",
+            expect=None),
+    4: dict(key="c4_full", m=59000000, n=64000000, related=False, nw=False, cfg=5, est_s=260,
+            workload="BASELINE config 4 at full size: %dx%d unrelated random ACGT, local SW, score + canonical position, 4 column bands",
+            expect={"i": 30491425, "j": 3008203, "score": 26, "source": "profiles/r02_scale_c4_chain_59Mx64M_4bands.json (4 bands, one GPU)"}),
+    8: dict(key="c5_full", m=249000000, n=228000000, related=True, nw=True, cfg=5, est_s=600,
+            workload="BASELINE config 5 at full size: %dx%d related synthetic pair, global NW, gap-initialised borders, block pruning on, 8 column bands",
+            expect={"i": 249000000, "j": 228000000, "score": 134862766, "source": "profiles/r05_nw_c5_249Mx228M_one_gpu_2048rows.json (one GPU, 1550 s)"}),
+}
+
+
+def full_config_for(world, rehearse=False):
+    """the BASELINE configuration `--gpus world` runs once behind its timed steps, or None (N = 1: c3_full; other N: none)"""
+    c = FULL_CONFIGS.get(world)
+    if c is None:
+        return None
+    c = dict(c)
+    if rehearse:
+        c["m"], c["n"] = c["m"] // 16, c["n"] // 16
+        c["expect"] = None
+        c["est_s"] = 30
+    c["workload"] = c["workload"] % (c["m"], c["n"])
+    return c
+
+
 def launch_check(args):
     """--launch-check: what the launcher needs to work, without a GPU -- every rank joins a gloo group over the rendezvous it
     was handed, the ranks add up their numbers, rank 0 prints one line.  (CPU test of the self-launch branch.)"""
@@ -195,22 +237,37 @@ def launch_check(args):
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    # The collectives backend of the real run: "nccl" (= RCCL) when every rank has a device of its own, gloo otherwise (no GPU
+    # here, or fewer devices than ranks: a one-GPU box).  torch.cuda.device_count() does not initialise the GPU.
+    backend = launch_check_backend(world, torch.cuda.device_count(), os.environ.get("MI355SW_LAUNCH_CHECK_BACKEND"))
+    device = torch.device("cpu")
+    if backend == "nccl":
+        torch.cuda.set_device(local_rank)
+        device = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("gloo", rank=rank, world_size=world)
-    t = torch.tensor([rank + 1], dtype=torch.int64)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)     # the call main() makes
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+    t = torch.tensor([rank + 1], dtype=torch.int64, device=device)
     if world > 1:
         dist.all_reduce(t)
     if args.launch_check_sleep > 0:
         time.sleep(args.launch_check_sleep)
     if rank == 0:
         print(json.dumps({"launch_check": True, "world": world, "gpus": args.gpus, "sum_of_ranks": int(t.item()),
+                          "backend": backend if world > 1 else "none", "devices_visible": torch.cuda.device_count(),
                           "launcher": os.environ.get("MI355SW_BENCH_LAUNCHER", "external"),
                           "master": "%s:%s" % (os.environ.get("MASTER_ADDR"), os.environ.get("MASTER_PORT"))}), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
     return 0
+
+
+T_BENCH_START = time.time()
 
 
 def main():
@@ -238,6 +295,8 @@ def main():
     ap.add_argument("--no-c3-full", action="store_true", help="N = 1: skip BASELINE config 3's stage 1 at full size (c3_full, about two minutes)")
     ap.add_argument("--no-single-reference", action="store_true",
                     help="N > 1: skip rank 0's untimed run of ONE GPU's share of the cells (tall*size x size) alone")
+    ap.add_argument("--no-full-config", action="store_true",
+                    help="N = 2, 4, 8: skip BASELINE's multi-GPU configuration run once behind the timed steps (c4_half / c4_full / c5_full)")
     ap.add_argument("--launch-check", action="store_true",
                     help="only check the launcher: the ranks meet over gloo, rank 0 prints one line (runs without a GPU)")
     ap.add_argument("--launch-check-sleep", type=float, default=0.0, help=argparse.SUPPRESS)
@@ -494,6 +553,26 @@ def main():
             for k, r in enumerate(ranks):
                 r.update(kernel_ms=band_stats[k]["kernel_ms"], wait_for_left_neighbour_ms=band_stats[k].get("wait_ms", 0.0),
                          pruned_cells=band_stats[k]["pruned_cells"], restarts=attach_chain.restarts, driven_by_rank=0)
+    # BASELINE's own multi-GPU configuration for this N, once, behind the timed steps (collective: every rank takes part; whatever
+    # goes wrong in it is reported inside the line, it never costs the headline)
+    full_cfg, full_out = None, None
+    if world > 1 and not args.no_full_config:
+        full_cfg = full_config_for(world, rehearse)
+    if full_cfg is not None:
+        budget = float(os.environ.get("MI355SW_BENCH_EXTRAS_MAX_S", "1800"))
+        verdict = [None]
+        if rank == 0 and (time.time() - T_BENCH_START) + full_cfg["est_s"] > budget:
+            verdict[0] = "skipped: %.0f s of the run gone, about %d s more would pass MI355SW_BENCH_EXTRAS_MAX_S = %.0f" % (
+                time.time() - T_BENCH_START, full_cfg["est_s"], budget)
+        dist.broadcast_object_list(verdict, src=0, group=p2p_group)
+        if verdict[0] is not None:
+            full_out = {"workload": full_cfg["workload"], "error": verdict[0]}
+        else:
+            al.close()                 # the headline's buffers and ports go back first
+            if attach_chain is not None:
+                for a2 in attach_chain.aligners:
+                    a2.close()
+            full_out = run_full_config(full_cfg, pkg, torch, dist, _Dist, p2p_group, world, rank, local_rank, comm, rehearse, waves, coll_device, args)
     if rank == 0:
         cells = float(m) * float(n)
         gcups = cells * args.steps / dt / 1e9
@@ -566,6 +645,8 @@ def main():
                 out["c3_full"] = c3_full(pkg, local_rank)
             except Exception as e:                       # noqa: BLE001
                 out["c3_full"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        if full_cfg is not None:
+            out[full_cfg["key"]] = full_out
         if world == 1 and not args.no_cpu_baseline:
             for key, fn in (("cpu_baseline", cpu_baseline), ("cpu_baseline_all_cores", cpu_baseline_mt)):
                 try:
@@ -577,6 +658,140 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def run_full_config(fc, pkg, torch, dist, make_dist, p2p_group, world, rank, local_rank, comm, rehearse, waves, coll_device, args):
+    """One of BASELINE's multi-GPU configurations (FULL_CONFIGS) through the band chain, once: the reference runs its real job
+    on N devices from one command line (--fork, M/libmasa/libmasa.cpp:540-642; block pruning switched off when it forks,
+    :1318-1321 -- here the bands share the running bound through their ports).  Every rank calls this; rank 0 gets the record.
+    A rank that fails says so to the others at the end (its neighbours' kernels give up after the wait budget), nobody hangs."""
+    import numpy as np
+    from masa_cudalign_amd.bands import BandRunner, InProcessChain, band_limits, rows_per_lane_for_bands, check_chain_bound
+    from masa_cudalign_amd.engine import NEEDLEMAN_WUNSCH, INIT_WITH_GAPS, INF
+    m, n, nw, related = fc["m"], fc["n"], fc["nw"], fc["related"]
+    out = {"workload": fc["workload"], "bands": world, "comm": comm}
+    err, best, al2, chain = None, (-1, -1, -INF), None, None
+    mine = {"rank": rank}
+    lim = band_limits(n, [1] * world)
+    j0, j1 = lim[rank], lim[rank + 1]
+    nwargs = argparse.Namespace(nw=nw, related=related)
+    try:
+        t0 = time.time()
+        s0, s1 = (pkg.seqgen.related_pair if related else pkg.seqgen.unrelated_pair)(m, n, cfg=fc["cfg"])
+        mine["generate_s"] = time.time() - t0
+        R = args.rows_per_lane or rows_per_lane_for_bands(m, lim[1] - lim[0], world, waves or 1024)
+        wait_s = float(os.environ.get("MI355SW_BENCH_EXTRA_WAIT_S", "900"))
+        if comm == "p2p-attach":
+            if rank == 0:
+                devs = [0] * world if rehearse else list(range(world))
+                als = [pkg.MI355Aligner(device=d, rows_per_lane=R, waves=waves, wait_seconds=wait_s) for d in devs]
+                for a2 in als:
+                    a2.setSequences(s0, s1)
+                chain = InProcessChain(als, prune_blocks=related)
+        else:
+            al2 = pkg.MI355Aligner(device=local_rank, rows_per_lane=R, waves=waves, wait_seconds=wait_s)
+            al2.setSequences(s0, s1)
+            runner = BandRunner(al2, dist=make_dist(), rank=rank, world=world, device=None, segment_rows=1 << 15, transport=comm, prune_blocks=related)
+            runner.stall_abort_s = wait_s
+    except Exception as e:                                   # noqa: BLE001
+        err = "set-up: %s: %s" % (type(e).__name__, e)
+    # everybody ready?  (a rank without its engine must not leave the others waiting in the chain)
+    ready = [None] * world
+    dist.all_gather_object(ready, err, group=p2p_group)
+    if any(ready):
+        out["error"] = "; ".join("rank %d: %s" % (r, w) for r, w in enumerate(ready) if w)
+        return out if rank == 0 else None
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.time()
+    try:
+        if comm == "p2p-attach":
+            if rank == 0:
+                best, sts = chain.run(m, lim, **_chain_kw(nwargs))
+                mine["bands"] = [{"kernel_ms": st["kernel_ms"], "wait_for_left_neighbour_ms": st.get("wait_ms", 0.0), "pruned_cells": st["pruned_cells"],
+                                  "seed_ms": st.get("seed_ms", 0.0), "strip_rows": st["strip_rows"], "kernel": st["kernel"]} for st in sts]
+                mine["restarts"], mine["initial_bound"] = chain.restarts, chain.initial_bound
+        else:
+            if nw:
+                got, last = {}, rank == world - 1
+                runner.run(m, j0, j1, n_total=n, recurrence=NEEDLEMAN_WUNSCH, track_best=False, first_row_init_type=INIT_WITH_GAPS,
+                           first_col_init_type=INIT_WITH_GAPS, want_last_row=last,
+                           before_end=(lambda eng: got.update(h=int(eng.streamReadLastRow(col=j1 - j0 - 1, length=1)[0, 0]))) if last else None)
+                best = (m - 1, n - 1, got["h"]) if last else (-1, -1, -INF)
+            else:
+                best = runner.run(m, j0, j1, n_total=n)
+            st = al2.getStatistics()
+            mine.update(kernel_ms=st["kernel_ms"], wait_for_left_neighbour_ms=st.get("wait_ms", 0.0), pruned_cells=st["pruned_cells"],
+                        seed_ms=st.get("seed_ms", 0.0), strip_rows=st["strip_rows"], kernel=st["kernel"], kernel_launches=st["kernel_launches"],
+                        band_columns=[j0, j1], band_best=[int(x) for x in best], restarts=runner.restarts, initial_bound=runner.initial_bound)
+    except Exception as e:                                   # noqa: BLE001
+        err = "%s: %s" % (type(e).__name__, e)
+    mine["seconds"] = time.time() - t0
+    mine["error"] = err
+    torch.cuda.synchronize()
+    recs = [None] * world
+    dist.all_gather_object(recs, mine, group=p2p_group)      # (also the fence behind the chain: every band is through)
+    dt = max(r["seconds"] for r in recs)
+    failed = [r for r in recs if r.get("error")]
+    if comm != "p2p-attach":
+        bests = [tuple(r.get("band_best", (-1, -1, -INF))) for r in recs]
+        from masa_cudalign_amd.bands import canonical_best
+        best = canonical_best(bests)
+    if rank == 0:
+        out["ranks"] = recs if comm != "p2p-attach" else recs[0].get("bands")
+        if failed:
+            out["error"] = "; ".join("rank %d: %s" % (r["rank"], r["error"]) for r in failed)
+        else:
+            bound = recs[0].get("initial_bound")
+            pruned = sum(r.get("pruned_cells", 0) for r in (recs if comm != "p2p-attach" else recs[0]["bands"]))
+            out.update({"value": float(m) * n / dt / 1e9, "unit": "GCUPS (m*n, one pass, seed included)", "seconds": dt,
+                        "best": {"i": best[0] + 1, "j": best[1] + 1, "score": best[2]}, "pruned_fraction": pruned / float(m) / n,
+                        "initial_bound": bound, "generate_s": recs[0].get("generate_s"),
+                        "xgmi": bool(comm in ("p2p", "p2p-attach") and not rehearse),
+                        "collectives": {"backend": dist.get_backend(), "world": dist.get_world_size()}})
+            check = {}
+            try:
+                if related:
+                    check_chain_bound(best[2], bound)
+                    check["not_below_the_bound_the_pruning_started_from"] = True
+            except Exception as e:                           # noqa: BLE001
+                check["not_below_the_bound_the_pruning_started_from"] = False
+                out["bound_error"] = str(e)
+            exp = fc.get("expect")
+            if exp is not None:
+                check["equals_the_recorded_one_gpu_run"] = (best[0] + 1, best[1] + 1, best[2]) == (exp["i"], exp["j"], exp["score"])
+                out["expect"] = exp
+            else:
+                # nothing recorded at this size (rehearsal): the chain must report what ONE band over all columns reports
+                try:
+                    al1 = pkg.MI355Aligner(device=local_rank, waves=waves)
+                    try:
+                        al1.setSequences(s0, s1)
+                        want = _single_band(pkg, al1, m, n, nwargs)
+                    finally:
+                        al1.close()
+                    check["equals_one_band_over_all_columns"] = tuple(int(x) for x in want) == tuple(int(x) for x in best)
+                except Exception as e:                       # noqa: BLE001
+                    check["equals_one_band_over_all_columns"] = False
+                    out["single_band_error"] = "%s: %s" % (type(e).__name__, e)
+            if not nw and best[1] >= 0:
+                # the reported cell under the oracle: the 600 x 600 window that ends at it
+                try:
+                    oracle = graft.load_oracle()
+                    i, j = best[0] + 1, best[1] + 1
+                    i0, jj0 = max(0, i - 600), max(0, j - 600)
+                    ref = oracle.stage1(s0[i0:i], s1[jj0:j], want_last_row=True)
+                    check["oracle_window_600x600_ending_at_the_cell"] = bool(ref["best"][2] == best[2] and int(ref["last_row"][-1][0]) == best[2])
+                except Exception as e:                       # noqa: BLE001
+                    out["oracle_error"] = "%s: %s" % (type(e).__name__, e)
+            check["ok"] = all(v for v in check.values() if isinstance(v, bool)) and len(check) > 0
+            out["check"] = check
+    for a2 in ([al2] if al2 is not None else []) + (chain.aligners if chain is not None else []):
+        try:
+            a2.close()
+        except Exception:                                    # noqa: BLE001
+            pass
+    return out if rank == 0 else None
 
 
 def _chain_kw(args):

@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define MI355SW_ABI_VERSION 7
+#define MI355SW_ABI_VERSION 8
 
 /* M/libmasa/libmasaTypes.hpp:35-41  cell_t {int h; union{int f; int e;};} 8-byte aligned */
 typedef struct { int32_t h; int32_t f; } mi355sw_cell;
@@ -87,7 +87,12 @@ typedef struct {
     int32_t stream_priority; /* 0 = the kernel stream gets the highest priority (default), 1 = normal, 2 = lowest */
     const char* trace_path;  /* per-strip timing records of every stream are written to this file (tools/trace_hops.py); NULL = off.
                                 The string is copied. */
-    int64_t reserved_[4];    /* zero */
+    int32_t batch_rows_per_lane; /* strip height of mi355sw_align_partitions' ONE launch, as rows_per_lane: 4 (256-row strips, the
+                                default: many small partitions stopped early -- stage 3's walks), 8 (512) or 16 (1024: a batch
+                                of tall partitions is throughput-bound and wants tall strips -- stage 2's sweeps from guessed
+                                crosspoints).  0 = 4 */
+    int32_t reserved32_;     /* zero */
+    int64_t reserved_[3];    /* zero */
 } mi355sw_config;
 #define MI355SW_F_FORCE_GENERIC_COMPARE 1   /* raw byte compare kernels even if a profile fits */
 #define MI355SW_F_FORCE_INT32 2             /* never use the packed 16-bit SW kernel */
@@ -107,10 +112,12 @@ typedef struct {
                                                skipped cell (A/B measurements, tests) */
 #define MI355SW_F_STAIRCASE_SEED 2048       /* the diagonal seed as ONE chain of tiles down the diagonal (the round-4 form) instead of
                                                segments between anchors swept side by side (A/B measurements, tests) */
-#define MI355SW_F_GENERATE_GAP_COLUMNS 4096  /* mi355sw_align_partition makes a gap-initialised first column on the device (recognised from the
-                                               first cells of the manager's stream) instead of taking it from that stream cell by cell.
-                                               Opt-in: faster for tall partitions stopped by their goal and for batches, slower for many
-                                               small partitions one after the other (see runtime.cpp, AlignJob::setup) */
+#define MI355SW_F_GENERATE_GAP_COLUMNS 4096  /* (ABI 7's opt-in; the DEFAULT since ABI 8 -- accepted and ignored) */
+#define MI355SW_F_STREAM_GAP_COLUMNS 8192   /* mi355sw_align_partition takes a gap-initialised first column from the manager's stream cell
+                                               by cell, like any other column, instead of recognising it from its first cells and making it
+                                               on the device (InitialCellsReader is a function of the position).  The default became
+                                               possible with the stop every strip sees at once (KernelArgs::stop_word): with all rows there
+                                               from the start hundreds of strips are in flight when the manager says stop (A/B, tests) */
 #define MI355SW_F_NO_HOST_COUNTER 512       /* the kernel does not mirror its strip counter into host memory (measurements) */
 #define MI355SW_V_MESSAGES 1                /* one line per noteworthy event (overflow reruns, the diagonal seed, ...) */
 #define MI355SW_V_JOBS 2                    /* timing of every mi355sw_align_partition job */

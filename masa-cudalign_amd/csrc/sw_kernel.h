@@ -43,6 +43,10 @@ struct KernelArgs {
     int* abort_flag;             // device word: the kernel sets it on an overflow report; strips claimed afterwards are skipped
     const int* host_abort;       // pinned host word: the host sets it != 0 to stop (mustContinue() == false) -- a store,
                                  // not a copy, because no copy may be queued while the persistent kernel runs
+    int* stop_word;              // device word: the first wavefront that sees the host's stop sets it, every strip looks at it
+                                 // once per chunk and wherever it waits -- all strips in flight end together, like the blocks
+                                 // of AbstractDiagonalAligner::alignPartition (mustContinue() per diagonal, :64), instead of one
+                                 // after the other at their own polls of the host's word
     int* error_flag;             // set by the kernel on a bounded-spin timeout
     const int* first_col_ready;  // counter of first_col rows that are valid (system scope), or nullptr (all): pinned host
                                  // memory when the host feeds the column, this GPU's HBM (fine-grained) when the
@@ -132,7 +136,7 @@ static __device__ __attribute__((noinline, unused)) void wait_first_column_commo
         bool ok = true, stop = false;
         int it = 0;
         while (sync::poll_dev(prog_in) < 1) {
-            if (sync::poll_dev(a->abort_flag) != 0) { stop = true; break; }
+            if (sync::poll_dev(a->abort_flag) != 0 || sync::poll_dev(a->stop_word) != 0) { stop = true; break; }
             if ((++it & 255) == 0) {
                 if (a->host_abort != nullptr && sync::poll_system(a->host_abort) != 0) { stop = true; break; }
                 if (__builtin_amdgcn_s_memrealtime() - t0 > budget) { ok = false; break; }
@@ -142,7 +146,7 @@ static __device__ __attribute__((noinline, unused)) void wait_first_column_commo
         long long need = (long long) a->strip_row0 + (long long) (s + 1) * strip_rows;
         if (need > a->m) need = a->m;
         while (ok && !stop && sync::poll_system(a->first_col_ready) < (int) need) {
-            if (sync::poll_dev(a->abort_flag) != 0) break;
+            if (sync::poll_dev(a->abort_flag) != 0 || sync::poll_dev(a->stop_word) != 0) break;
             if ((++it & 63) == 0) {
                 if (a->host_abort != nullptr && sync::poll_system(a->host_abort) != 0) break;
                 if (__builtin_amdgcn_s_memrealtime() - t0 > budget) { ok = false; break; }
@@ -207,7 +211,8 @@ static __device__ __attribute__((noinline, unused)) void complete_strip_common(c
         __builtin_amdgcn_s_sleep(8);
         spins++;
         if (stopped_waves_leave && (spins & 31) == 0 &&
-            (sync::poll_dev(a->abort_flag) != 0 || (a->host_abort != nullptr && sync::poll_system(a->host_abort) != 0))) { gone = true; break; }
+            (sync::poll_dev(a->abort_flag) != 0 || sync::poll_dev(a->stop_word) != 0 ||
+             (a->host_abort != nullptr && sync::poll_system(a->host_abort) != 0))) { gone = true; break; }
     }
     if (lane == 0) {
         // (never over a report that is already there: an overflow code 16 must reach the host as such)

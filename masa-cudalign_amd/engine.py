@@ -26,7 +26,8 @@ ERRORS = {-1: "EINVAL", -2: "EHIP", -3: "ENOGPU", -4: "ENOMEM", -5: "ETIMEOUT", 
 # mi355sw_config.flags / .verbosity (include/mi355sw.h)
 F_FORCE_GENERIC_COMPARE, F_FORCE_INT32, F_NO_DIAGONAL_SEED, F_NO_SEED_PASS, F_NO_PRUNE_PROBE = 1, 2, 4, 8, 16
 F_TWO_PHASE, F_NO_MIXED, F_NO_SHARED_BEST, F_NO_BATCH, F_NO_HOST_COUNTER, F_NO_WINDOW, F_STAIRCASE_SEED = 32, 64, 128, 256, 512, 1024, 2048
-F_GENERATE_GAP_COLUMNS = 4096
+F_GENERATE_GAP_COLUMNS = 4096      # (ABI 7's opt-in; the default since ABI 8, accepted and ignored)
+F_STREAM_GAP_COLUMNS = 8192        # gap-initialised first columns taken from the manager's stream instead of made on the device
 V_MESSAGES, V_JOBS, V_SEED_TILES, V_BATCH, V_DEBUG_WORDS = 1, 2, 4, 8, 16
 
 # The C library reads no environment variable (ABI 7): the MI355SW_* switches live HERE, in the Python front, and are
@@ -35,7 +36,7 @@ V_MESSAGES, V_JOBS, V_SEED_TILES, V_BATCH, V_DEBUG_WORDS = 1, 2, 4, 8, 16
 _ENV_FLAGS = {"MI355SW_NO_DIAGONAL_SEED": F_NO_DIAGONAL_SEED, "MI355SW_NOSEED": F_NO_SEED_PASS, "MI355SW_NO_PRUNE_PROBE": F_NO_PRUNE_PROBE,
               "MI355SW_TWO_PHASE": F_TWO_PHASE, "MI355SW_NO_MIXED": F_NO_MIXED, "MI355SW_NO_SHARED_BEST": F_NO_SHARED_BEST,
               "MI355SW_NO_BATCH": F_NO_BATCH, "MI355SW_NOHOST": F_NO_HOST_COUNTER, "MI355SW_NO_WINDOW": F_NO_WINDOW, "MI355SW_STAIRCASE_SEED": F_STAIRCASE_SEED,
-              "MI355SW_GENERATE_GAP_COLUMNS": F_GENERATE_GAP_COLUMNS}
+              "MI355SW_STREAM_GAP_COLUMNS": F_STREAM_GAP_COLUMNS}
 _ENV_VERBOSITY = {"MI355SW_VERBOSE": V_MESSAGES, "MI355SW_VERBOSE_JOBS": V_JOBS, "MI355SW_VERBOSE_TILES": V_SEED_TILES,
                   "MI355SW_BATCH_DEBUG": V_BATCH, "MI355SW_DEBUG": V_DEBUG_WORDS}
 
@@ -94,7 +95,8 @@ class Config(C.Structure):
     _fields_ = [("device", C.c_int32), ("rows_per_lane", C.c_int32), ("waves", C.c_int32),
                 ("flags", C.c_int32), ("max_special_bytes", C.c_int64), ("block_score_columns", C.c_int32),
                 ("verbosity", C.c_int32), ("wait_seconds", C.c_double), ("fault_overflow_strip_plus1", C.c_int32),
-                ("stream_priority", C.c_int32), ("trace_path", C.c_char_p), ("reserved_", C.c_int64 * 4)]
+                ("stream_priority", C.c_int32), ("trace_path", C.c_char_p), ("batch_rows_per_lane", C.c_int32), ("reserved32_", C.c_int32),
+                ("reserved_", C.c_int64 * 3)]
 
 
 class Capabilities(C.Structure):
@@ -374,12 +376,13 @@ class MI355Aligner:
         cfg.fault_overflow_strip_plus1 = o.get("fault_overflow_strip_plus1", 0) or efault
         cfg.stream_priority = eprio
         cfg.trace_path = etrace.encode() if etrace else None
+        cfg.batch_rows_per_lane = o.get("batch_rows_per_lane", 0)
         return cfg
 
     @staticmethod
     def _config_key(cfg):
         return (cfg.rows_per_lane, cfg.waves, cfg.flags, cfg.max_special_bytes, cfg.block_score_columns, cfg.verbosity, cfg.wait_seconds,
-                cfg.fault_overflow_strip_plus1, cfg.trace_path)
+                cfg.fault_overflow_strip_plus1, cfg.trace_path, cfg.batch_rows_per_lane)
 
     def _sync_config(self):
         """hand the library the switches as they are NOW (constructor arguments, configure(), the MI355SW_* environment)"""
@@ -391,10 +394,10 @@ class MI355Aligner:
 
     def configure(self, **kw):
         """change switches of a live engine: flags, verbosity, wait_seconds, waves, rows_per_lane, max_special_bytes,
-        block_score_columns, fault_overflow_strip_plus1 (mi355sw_configure; no stream may be active)"""
+        block_score_columns, fault_overflow_strip_plus1, batch_rows_per_lane (mi355sw_configure; no stream may be active)"""
         for k in kw:
             if k not in ("flags", "verbosity", "wait_seconds", "waves", "rows_per_lane", "max_special_bytes", "block_score_columns",
-                         "fault_overflow_strip_plus1"):
+                         "fault_overflow_strip_plus1", "batch_rows_per_lane"):
                 raise TypeError("configure: unknown option %r" % k)
         self._opts.update(kw)
         if "rows_per_lane" in kw:
@@ -471,13 +474,23 @@ class MI355Aligner:
             raise manager._callback_error
         del keep
 
-    def alignPartitions(self, partitions, managers):
+    batch_rows_per_lane_choices = (4, 8, 16)      # mi355sw_config.batch_rows_per_lane
+
+    def alignPartitions(self, partitions, managers, rows_per_lane=None):
         """mi355sw_align_partitions: independent partitions side by side in one kernel launch; managers[k] is served
-        exactly as alignPartition(partitions[k], managers[k]) would serve it, the calls of different managers interleave"""
+        exactly as alignPartition(partitions[k], managers[k]) would serve it, the calls of different managers interleave.
+        rows_per_lane: strip height of THIS launch (mi355sw_config.batch_rows_per_lane: 4, 8 or 16 = 256 / 512 / 1024 rows)"""
         n = len(partitions)
         assert n == len(managers)
         if n == 0:
             return
+        if rows_per_lane is not None:
+            saved = self._opts.get("batch_rows_per_lane", 0)
+            self._opts["batch_rows_per_lane"] = int(rows_per_lane)
+            try:
+                return self.alignPartitions(partitions, managers)
+            finally:
+                self._opts["batch_rows_per_lane"] = saved
         self._sync_config()
         parts = (Partition * n)(*[Partition(p.i0, p.j0, p.i1, p.j1) for p in partitions])
         tables, keeps = zip(*[make_manager_table(m) for m in managers])

@@ -313,6 +313,21 @@ def _shorten(fn, size):
         os.truncate(fn, size)
 
 
+SCRATCH_PREFIX = "guess."             # partitions of sweeps nobody has accepted yet (SpecialRowsArea.create_partition(scratch=True))
+
+
+def _remove_tree(path):
+    """a discarded partition's directory; what cannot be removed is said (a stale directory under a partition's own name would
+    be opened by a later stage: scratch partitions therefore never carry such a name, see SCRATCH_PREFIX)"""
+    import shutil
+    import sys
+
+    def complain(fn, p, exc):
+        sys.stderr.write("[sra] could not remove %s: %s\n" % (p, exc[1] if isinstance(exc, tuple) else exc))
+    if os.path.isdir(path):
+        shutil.rmtree(path, onerror=complain)
+
+
 def _move_directory(old, new):
     if os.path.isdir(new):             # left by an earlier run of the same stage in this work directory
         import shutil
@@ -326,7 +341,7 @@ class SpecialRowsPartition:
     partition without a path (SpecialRowsArea::getPartitionPath returns "" for non-persistent areas): it takes the
     border readers and drops every row."""
 
-    def __init__(self, area_path, i0, j0, i1, j1, read_only=False, persistent=True):
+    def __init__(self, area_path, i0, j0, i1, j1, read_only=False, persistent=True, scratch=False):
         self.i0, self.j0, self.i1, self.j1 = i0, j0, i1, j1
         self.read_only, self.persistent = read_only, persistent
         self.first_row_reader = self.first_column_reader = None
@@ -348,7 +363,7 @@ class SpecialRowsPartition:
         if not persistent:
             self.path = ""
             return
-        self.path = os.path.join(area_path, "%08X.%08X.%08X.%08X" % (i0, j0, i1, j1))
+        self.path = os.path.join(area_path, (SCRATCH_PREFIX if scratch else "") + "%08X.%08X.%08X.%08X" % (i0, j0, i1, j1))
         if read_only:
             _files.drain()
             if not os.path.isdir(self.path):
@@ -607,8 +622,11 @@ class SpecialRowsArea:
     def set_persistent(self, persistent):
         self.persistent = persistent
 
-    def create_partition(self, i0, j0, i1, j1):
-        p = SpecialRowsPartition(self.directory, i0, j0, i1, j1, persistent=self.persistent)
+    def create_partition(self, i0, j0, i1, j1, scratch=False):
+        """scratch: under a name open_partition_at does not look for ("guess.<rectangle>": stage 2's sweeps from guessed
+        crosspoints) -- such a partition only gets its place among the stage's partitions when truncate_partition moves it
+        there; what a killed run leaves of them is removed by remove_scratch_partitions"""
+        p = SpecialRowsPartition(self.directory, i0, j0, i1, j1, persistent=self.persistent, scratch=scratch)
         p.set_ram_proportion(self.ram_limit, self.disk_limit)
         if self.persistent:
             self.partitions[p.path] = p
@@ -651,6 +669,19 @@ class SpecialRowsArea:
             self.partitions[new] = p
         self.rows += p.rows_count()
 
+    def remove_scratch_partitions(self):
+        """leftovers of sweeps from guessed crosspoints (a run that died between its batch and its walk)"""
+        import shutil
+        _files.drain()
+        if not os.path.isdir(self.directory):
+            return 0
+        gone = 0
+        for name in os.listdir(self.directory):
+            if name.startswith(SCRATCH_PREFIX):
+                shutil.rmtree(os.path.join(self.directory, name), ignore_errors=True)
+                gone += 1
+        return gone
+
     def discard_partition(self, p):
         """a partition nobody is going to read (stage 2's sweep from a crosspoint guess that turned out wrong): its rows, its
         directory and its entry go away -- no counterpart in the reference, which never sweeps on a guess"""
@@ -660,7 +691,7 @@ class SpecialRowsArea:
             import shutil
             if self.partitions.get(p.path) is p:
                 del self.partitions[p.path]
-            _files.submit(p, shutil.rmtree, p.path, True)
+            _files.submit(p, _remove_tree, p.path)
 
     def rows_count(self):
         """(:97-103)"""

@@ -32,9 +32,11 @@ def _as_u8(seq):
     return np.frombuffer(bytes(seq), dtype=np.uint8) if isinstance(seq, (bytes, bytearray)) else np.asarray(seq, dtype=np.uint8)
 
 
-def prepare_next_crosspoint(mgr, area, c0, c1, alignment_start, must_find=True, goal_location=None):
+def prepare_next_crosspoint(mgr, area, c0, c1, alignment_start, must_find=True, goal_location=None, scratch=False):
     """the set-up of find_next_crosspoint: goal, borders and special-rows partition of the sweep c0 -> c1.  Returns
-    (special-rows partition, partition for the aligner or None if the manager met the goal without it)."""
+    (special-rows partition, partition for the aligner or None if the manager met the goal without it).
+    scratch: the special-rows partition is made under a name no reader looks for (a sweep from a guessed crosspoint: it
+    moves into place when the walk accepts it, SpecialRowsArea.truncate_partition)."""
     first_row = InitialCellsReader(0 if c0.type == TYPE_GAP_1 else GAP_OPEN, GAP_EXT)
     first_col = InitialCellsReader(0 if c0.type == TYPE_GAP_2 else GAP_OPEN, GAP_EXT)
     if not must_find:
@@ -45,7 +47,7 @@ def prepare_next_crosspoint(mgr, area, c0, c1, alignment_start, must_find=True, 
         mgr.setGoalScore(c0.score, AT_ANYWHERE)          # short enough to hold the alignment's start
     else:
         mgr.setGoalScore(c0.score, AT_SEQUENCE_1_OR_2)
-    part = area.create_partition(c0.i, c0.j, c1.i, c1.j)
+    part = area.create_partition(c0.i, c0.j, c1.i, c1.j, scratch=scratch)
     part.set_first_column_reader(first_col)
     part.set_first_row_reader(first_row)
     mgr.setSpecialRowsPartition(part)
@@ -167,22 +169,32 @@ class _Speculation:
             for c0, t, guess in chain:
                 c0_r = c0.reverse(len_v, len_h)
                 c1 = Crosspoint(len_v - part1.j0, len_h - (part1.i0 + ids[t]))
-                m = _GuessManager.of(mgr, 2 * (c1.j - c0.j) + 4096) if guess else mgr.clone()
+                # A guessed sweep is given up `cap` rows down its last column at the latest (_GuessManager), so its partition
+                # need not be taller than that: the engine sizes its buffers -- first column, special rows of its own -- by
+                # the partition's height, and dozens of sweeps as tall as what is left of the sequence (C3: 22 M rows, 15 GB of
+                # special-row room each) do not fit side by side.  The rows above the cut do not depend on what lies below.
+                cap = 2 * (c1.j - c0.j) + 4096
+                c1p = Crosspoint(min(c1.i, c0.i + cap + 16384), c1.j) if guess else c1
+                m = _GuessManager.of(mgr, cap) if guess else mgr.clone()
                 row = sra_mod.SpecialRowReader(part1, ids[t])
                 row.seek(abs(c0_r.j - part1.j0) + 1)
                 m.setLastColumnReader(row)
-                if col_reader is not None:
+                if col_reader is not None and c1p.i == c1.i:      # (a cut partition's last row is not the matrix's border)
                     col = ReversedCellsReader(col_reader)
                     col.seek(c0_r.i - part1.i0 + 1)
                     m.setLastRowReader(col)
-                part, adj = prepare_next_crosspoint(m, area, c0, c1, alignment_start)
+                part, adj = prepare_next_crosspoint(m, area, c0, c1p, alignment_start, scratch=guess)
                 sw = dict(mgr=m, part=part, c0=c0, c1=c1, guess=guess)
                 self.sweeps[(c0.astuple(), c1.astuple())] = sw
                 if adj is not None:
                     jobs.append((m, adj))
             self.made = len(self.sweeps)
             if len(jobs) > 1 and hasattr(mgr.aligner, "alignPartitions"):
-                mgr.aligner.alignPartitions([a for _, a in jobs], [m for m, _ in jobs])
+                # tall strips: a batch of sweeps that run to their goals hundreds of thousands of rows down is throughput-bound
+                # (1024-row strips: 4.6 TCUPS against the 2.7 of the 256-row strips stage 3's small partitions get), and 1024
+                # keeps the rows this stage stores for stage 3 on CUDAlign's 8192-row grid like the chain's 512
+                kw = {"rows_per_lane": 16} if 16 in getattr(mgr.aligner, "batch_rows_per_lane_choices", ()) else {}
+                mgr.aligner.alignPartitions([a for _, a in jobs], [m for m, _ in jobs], **kw)
             else:
                 for m, a in jobs:
                     mgr.aligner.alignPartition(a, m)
@@ -251,6 +263,8 @@ def stage2(aligner, seq0, seq1, work, alignment_start=AT_ANYWHERE, sra_limit=0, 
         mgr.setSpecialRowInterval(sra_mod.flush_intervals(m, n, budget)[1])
     else:
         mgr.setSpecialRowInterval(0)
+    if speculate:
+        area2.remove_scratch_partitions()                # (what a run that died between its batch and its walk left behind)
     out = CrosspointsFile(crosspoint_file(work, 2, ident)).open()
     out.write(cp)
     if cp.type != TYPE_MATCH:

@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol(pkg):
         assert hasattr(lib, name), name
     assert sorted(pkg.engine.ABI_SYMBOLS) == names
     lib.mi355sw_abi_version.restype = ctypes.c_int
-    assert lib.mi355sw_abi_version() == 7
+    assert lib.mi355sw_abi_version() == 8
 
 
 def test_struct_layouts_match_reference_types(pkg):

@@ -59,3 +59,44 @@ def test_a_rank_environment_is_respected():
     rec = json.loads(p.stdout.decode().strip().splitlines()[-1])
     assert rec["world"] == 1 and rec["launcher"] == "external"
     assert b"starting" not in p.stderr
+
+
+def _bench_module():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_under_test", BENCH)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_launch_check_joins_the_real_runs_backend_when_the_devices_are_there():
+    """--launch-check initialises "nccl" (= RCCL, the call bench.main makes) as soon as there is one device per rank and stays
+    on gloo otherwise (this container: no GPU; a one-GPU box under --gpus 2)."""
+    b = _bench_module()
+    assert b.launch_check_backend(8, 8) == "nccl" and b.launch_check_backend(4, 8) == "nccl"
+    assert b.launch_check_backend(2, 1) == "gloo" and b.launch_check_backend(2, 0) == "gloo"
+    assert b.launch_check_backend(1, 8) == "gloo"                   # one rank: no group at all
+    assert b.launch_check_backend(2, 0, forced="nccl") == "nccl" and b.launch_check_backend(8, 8, forced="gloo") == "gloo"
+    p = _run(["--gpus", "2", "--launch-check"])
+    rec = json.loads(p.stdout.decode().strip().splitlines()[-1])
+    assert rec["backend"] == "gloo" and rec["devices_visible"] == 0 and rec["sum_of_ranks"] == 3
+
+
+def test_the_gpus_n_line_runs_baselines_own_multi_gpu_configuration():
+    """--gpus 4 -> BASELINE config 4 (59 M x 64 M unrelated SW, 4 bands), --gpus 8 -> config 5 (249 M x 228 M related NW with
+    pruning, 8 bands), --gpus 2 -> C4's first two bands; other N none; a rehearsal runs them at 1/16 of the linear size."""
+    b = _bench_module()
+    c4, c5, c2 = b.full_config_for(4), b.full_config_for(8), b.full_config_for(2)
+    assert (c4["key"], c4["m"], c4["n"], c4["related"], c4["nw"]) == ("c4_full", 59000000, 64000000, False, False)
+    assert (c5["key"], c5["m"], c5["n"], c5["related"], c5["nw"]) == ("c5_full", 249000000, 228000000, True, True)
+    assert (c2["key"], c2["m"], c2["n"]) == ("c4_half", 59000000, 32000000)
+    assert c4["expect"]["score"] == 26 and c5["expect"]["score"] == 134862766
+    assert "59000000x64000000" in c4["workload"] and "249000000x228000000" in c5["workload"]
+    assert b.full_config_for(1) is None and b.full_config_for(3) is None and b.full_config_for(16) is None
+    r = b.full_config_for(8, rehearse=True)
+    assert (r["m"], r["n"], r["expect"]) == (249000000 // 16, 228000000 // 16, None)
+    # the recorded values are the ones under profiles/
+    rec4 = json.load(open(os.path.join(ROOT, "profiles", "r02_scale_c4_chain_59Mx64M_4bands.json")))
+    assert (rec4["best"]["i"], rec4["best"]["j"], rec4["best"]["score"]) == (c4["expect"]["i"], c4["expect"]["j"], c4["expect"]["score"])
+    rec5 = json.load(open(os.path.join(ROOT, "profiles", "r05_nw_c5_249Mx228M_one_gpu_2048rows.json")))
+    assert rec5["h_last_cell"] == c5["expect"]["score"]

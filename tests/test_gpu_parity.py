@@ -480,8 +480,12 @@ def test_stop_like_stage2_goal_found(pkg, oracle):
     row = np.zeros((n + 1, 2), dtype=np.int32); row[:, 0] = -2 * np.arange(n + 1) - 3; row[0, 0] = 0; row[:, 1] = -INF
 
     class CountingReader(ArrayCellsReader):
+        asked, asked_after_stop, stopped = 0, 0, False
+
         def read(self, buf, length):
-            self.asked = getattr(self, "asked", 0) + length
+            self.asked += length
+            if self.stopped:
+                self.asked_after_stop += length
             return ArrayCellsReader.read(self, buf, length)
 
     class Mgr(pkg.Stage1Manager):
@@ -489,6 +493,7 @@ def test_stop_like_stage2_goal_found(pkg, oracle):
             pkg.Stage1Manager.dispatchColumn(self, j, buf, length)
             if self.last_column_pos >= stop_after:
                 self.active = False                      # AlignerManager::stopAligner, AlignerManager.cpp:357-370
+                creader.stopped = True
 
     creader = CountingReader(col)
     al = pkg.MI355Aligner(device=0)
@@ -517,8 +522,11 @@ def test_stop_like_stage2_goal_found(pkg, oracle):
     want = dict(zip(ref["special_row_ids"], ref["special_rows"]))
     for r in rows:
         assert np.array_equal(mg.specialRow(r), want[r]), r
-    assert creader.asked < m // 2                       # the first-column stream was left alone after the stop
-    assert st["processed_cells"] < 0.6 * m * n          # and much of the partition was never computed
+    # the first-column stream is left alone after the stop, and the engine computes nothing below the rows it had been fed by
+    # then.  (Whatever else shares the GPU: how far the feed is ahead of the kernel when the stop comes is a matter of timing
+    # -- under `pytest -n 6` the whole column may be there before the kernel's first strip is through -- these two are not.)
+    assert creader.asked_after_stop == 0
+    assert st["processed_cells"] <= min(m, creader.asked + st["strip_rows"]) * n
 
 
 @pytest.mark.parametrize("rel", [False, True])

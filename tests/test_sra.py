@@ -322,3 +322,29 @@ def test_file_queue_starts_empty_in_a_forked_child(pkg):
     q.submit(None, done.append, 1)             # and works: a thread of this process is started
     q.drain()
     assert done == [1]
+
+
+def test_scratch_partitions_are_invisible_until_accepted(pkg, tmp_path):
+    """Sweeps from guessed crosspoints (stage2._Speculation) keep their rows under "guess.<rectangle>": open_partition_at never
+    finds such a directory, truncate_partition moves an accepted one to its real name, discard_partition removes a rejected one,
+    and what a killed run left is cleared by remove_scratch_partitions (a stale guess must not be opened as
+    a partition by a later stage)."""
+    sra = pkg.sra
+    area = sra.SpecialRowsArea(str(tmp_path / "area"))
+    os.makedirs(area.directory, exist_ok=True)
+    a = area.create_partition(0, 0, 4000, 300, scratch=True)
+    b = area.create_partition(0, 0, 5000, 300, scratch=True)
+    c = area.create_partition(10, 10, 6000, 300, scratch=True)
+    sra._files.drain()
+    names = sorted(os.listdir(area.directory))
+    assert len(names) == 3 and all(n.startswith("guess.") for n in names)
+    assert area.open_partition_at(100, 100) is None              # nothing a reader could pick up
+    area.truncate_partition(a, 1000, 200)                        # accepted: cut back to its crosspoint and moved into place
+    area.discard_partition(b)                                    # rejected
+    sra._files.drain()
+    names = sorted(os.listdir(area.directory))
+    assert names == sorted(["%08X.%08X.%08X.%08X" % (0, 0, 1000, 200), os.path.basename(c.path)])
+    p = area.open_partition_at(100, 100)
+    assert p is not None and (p.i1, p.j1) == (1000, 200)
+    assert area.remove_scratch_partitions() == 1                 # c: as if the run had died here
+    assert sorted(os.listdir(area.directory)) == ["%08X.%08X.%08X.%08X" % (0, 0, 1000, 200)]
