@@ -430,6 +430,12 @@ int mi355sw_stage6_text(const char* seq0, int32_t seq0_len, const char* seq1, in
                         int32_t i1, int32_t j1, const int32_t* gaps0, int32_t n_gaps0, const int32_t* gaps1, int32_t n_gaps1,
                         int64_t raw_score, char** text, int64_t* text_len, mi355sw_stage5_totals* totals);
 
+/* ---- crosspoint files as text ------------------------------------------------------------------------------------------
+ * Replaces CrosspointsFile::save / write (M/common/CrosspointsFile.cpp:99-160): "START", one "type,i,j,score" line per
+ * crosspoint, "END" -- the bytes of crosspoint_NN.II.  Host code (no handle, no GPU); `*text` is released with mi355sw_free
+ * and not NUL-counted in *text_len.  (crosspoint_04 of BASELINE config 3 is 4.6 M lines.) */
+int mi355sw_crosspoints_text(const mi355sw_crosspoint* points, int64_t count, char** text, int64_t* text_len);
+
 /* device enumeration: X/cuda_util.cpp:191-287 (--list-gpus, GPU weights) */
 int mi355sw_device_count(void);
 int mi355sw_device_info(int32_t device, char* name, size_t name_len, int32_t* compute_units, int32_t* clock_mhz, int64_t* hbm_bytes);

@@ -107,16 +107,12 @@ class CrosspointsFile(list):
 
 def save_array(filename, points):
     """CrosspointsFile::save (:152-160) for an (N, 4) array of (type, i, j, score): the same bytes as CrosspointsFile.save
-    writes for the same points, without a Python object per point"""
-    import numpy as np
-    pts = np.ascontiguousarray(points, dtype=np.int64).reshape(-1, 4)
+    writes for the same points, formatted by the library (mi355sw_crosspoints_text: crosspoint_04 of BASELINE config 3 is
+    4.6 M lines -- 2-4 s of "%d,%d,%d,%d" in Python, a tenth of a second there)"""
+    from .engine import crosspoints_text
     tmp = filename + ".tmp"
-    with open(tmp, "w") as f:
-        f.write("START\n")
-        step = 1 << 18
-        for k in range(0, len(pts), step):
-            f.write("".join(["%d,%d,%d,%d\n" % tuple(r) for r in pts[k:k + step].tolist()]))
-        f.write("END\n")
+    with open(tmp, "wb") as f:
+        f.write(crosspoints_text(points))
     os.replace(tmp, filename)
 
 

@@ -255,3 +255,34 @@ extern "C" int mi355sw_stage6_text(const char* seq0, int32_t seq0_len, const cha
     *text_len = (int64_t) out.size();
     return MI355SW_OK;
 }
+
+// ---- crosspoint files as text (CrosspointsFile::save, M/common/CrosspointsFile.cpp:99-160) ----------------------------------
+// "START\n", one "type,i,j,score\n" line per crosspoint, "END\n": crosspoint_04 of a 46 M-column alignment is 4.6 M lines
+// (130 MB), 2-4 s of formatting in the Python host and a tenth of a second here.
+extern "C" int mi355sw_crosspoints_text(const mi355sw_crosspoint* points, int64_t count, char** text, int64_t* text_len) {
+    if (!text || !text_len || count < 0 || (count > 0 && !points)) return MI355SW_EINVAL;
+    *text = nullptr; *text_len = 0;
+    // at most 4 numbers of 11 characters, 3 commas and a newline per line
+    char* buf = (char*) malloc((size_t) count * 48 + 16);
+    if (!buf) return MI355SW_ENOMEM;
+    char* w = buf;
+    memcpy(w, "START\n", 6); w += 6;
+    auto put = [&](long long v) {
+        char tmp[24];
+        int n = 0;
+        unsigned long long u = v < 0 ? (unsigned long long) (-v) : (unsigned long long) v;
+        do { tmp[n++] = (char) ('0' + u % 10); u /= 10; } while (u);
+        if (v < 0) *w++ = '-';
+        while (n) *w++ = tmp[--n];
+    };
+    for (int64_t k = 0; k < count; k++) {
+        put(points[k].type); *w++ = ',';
+        put(points[k].i); *w++ = ',';
+        put(points[k].j); *w++ = ',';
+        put(points[k].score); *w++ = '\n';
+    }
+    memcpy(w, "END\n", 4); w += 4;
+    *text = buf;
+    *text_len = (int64_t) (w - buf);
+    return MI355SW_OK;
+}

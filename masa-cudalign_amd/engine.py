@@ -189,7 +189,7 @@ ABI_SYMBOLS = [
     "mi355sw_stream_best_hint", "mi355sw_stream_running_best",
     "mi355sw_port_create", "mi355sw_port_open", "mi355sw_port_attach", "mi355sw_port_reset", "mi355sw_port_rows_ready", "mi355sw_port_read",
     "mi355sw_port_local_pointers", "mi355sw_port_close", "mi355sw_stage4", "mi355sw_free", "mi355sw_stage5", "mi355sw_stage6_text",
-    "mi355sw_device_count", "mi355sw_device_info",
+    "mi355sw_crosspoints_text", "mi355sw_device_count", "mi355sw_device_info",
 ]
 
 _lib = None
@@ -280,6 +280,7 @@ def load_library():
     lib.mi355sw_stage6_text.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                         C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int64, C.POINTER(C.c_void_p),
                                         C.POINTER(C.c_int64), C.POINTER(Stage5Totals)]
+    lib.mi355sw_crosspoints_text.argtypes = [C.c_void_p, C.c_int64, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
     lib.mi355sw_device_info.argtypes = [C.c_int32, C.c_char_p, C.c_size_t, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                         C.POINTER(C.c_int64)]
     _lib = lib
@@ -322,6 +323,20 @@ def stage6_body(forward0, forward1, start, end, gaps0, gaps1, raw_score):
         raise RuntimeError("Stage6 error: Alignment score is different (%d != %d)" % (tot.score, raw_score))
     if rc != 0:
         raise AlignerError("stage6: %s" % ERRORS.get(rc, rc))
+    try:
+        return C.string_at(text.value, n.value)
+    finally:
+        lib.mi355sw_free(text)
+
+
+def crosspoints_text(points):
+    """mi355sw_crosspoints_text (host code, no GPU): the bytes of a crosspoint file for an (N, 4) array of (type, i, j, score)"""
+    lib = load_library()
+    cp = np.ascontiguousarray(points, dtype=np.int32).reshape(-1, 4)
+    text, n = C.c_void_p(), C.c_int64()
+    rc = lib.mi355sw_crosspoints_text(cp.ctypes.data, len(cp), C.byref(text), C.byref(n))
+    if rc != 0:
+        raise AlignerError("crosspoints_text: %s" % ERRORS.get(rc, rc))
     try:
         return C.string_at(text.value, n.value)
     finally:
@@ -404,10 +419,16 @@ class MI355Aligner:
             self._rows_per_lane = int(kw["rows_per_lane"])
         self._sync_config()
 
-    def setFlag(self, bit, on=True):
-        """one MI355SW_F_* bit on or off for the calls that follow"""
+    def setFlag(self, bit, on=True, defer=False):
+        """one MI355SW_F_* bit on or off for the calls that follow.  defer: only noted here -- the library gets it with the
+        next call that starts work (_sync_config).  For clean-up paths: mi355sw_configure refuses while a stream is active,
+        and an error raised from a `finally` would replace the one that is on its way out."""
         f = self._opts["flags"]
-        self.configure(flags=(f | bit) if on else (f & ~bit))
+        f = (f | bit) if on else (f & ~bit)
+        if defer:
+            self._opts["flags"] = f
+        else:
+            self.configure(flags=f)
 
     def getFlags(self):
         return self._opts["flags"]

@@ -355,7 +355,7 @@ class SpecialRowsPartition:
         self.rows = []                 # ids (i - i0) of complete rows, ascending (the first row, id 0, is implicit)
         # id -> (largest H of the row, its cell index): kept while the rows are written when stage 2 is going to guess its
         # crosspoints from them (stage2.py, MI355SW_STAGE2_SPECULATE); lives with the object, i.e. for the stages of one process
-        self.track_peaks = bool(os.environ.get("MI355SW_STAGE2_SPECULATE"))
+        self.track_peaks = os.environ.get("MI355SW_STAGE2_SPECULATE", "1") not in ("", "0")
         self.peaks = {}
         self.reading = None            # SpecialRowReader handed out last
         self._reading_idx = 0

@@ -159,7 +159,7 @@ def stage1(aligner, seq0, seq1, work, alignment_start=AT_ANYWHERE, alignment_end
         aligner.alignPartition(rel, mgr)
     finally:
         if seed_off:
-            aligner.setFlag(F_NO_DIAGONAL_SEED, False)
+            aligner.setFlag(F_NO_DIAGONAL_SEED, False, defer=True)      # (handed over with the next call: nothing here may raise)
         stop_log()
         if part_sra is not None:
             part_sra.close()

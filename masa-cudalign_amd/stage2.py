@@ -28,6 +28,11 @@ MATCH_SCORE = 1
 MIN_ROW_DISTANCE = 128          # sw_stage2.cpp:420: special rows nearer than this to the crosspoint are skipped
 
 
+def speculation_default():
+    """stage 2 starts its sweeps side by side from guessed crosspoints (_Speculation) unless MI355SW_STAGE2_SPECULATE=0"""
+    return os.environ.get("MI355SW_STAGE2_SPECULATE", "1") not in ("", "0")
+
+
 def _as_u8(seq):
     return np.frombuffer(bytes(seq), dtype=np.uint8) if isinstance(seq, (bytes, bytearray)) else np.asarray(seq, dtype=np.uint8)
 
@@ -128,8 +133,10 @@ class _Speculation:
     (SpecialRowsArea.discard_partition), and the walk makes that one step the plain way.  The files of the stage do not
     change.  No counterpart in the reference (its stage 2 is the plain chain, sw_stage2.cpp:387-441).
 
-    Opt-in (stage2(speculate=True) or MI355SW_STAGE2_SPECULATE=1); the row maxima are recorded by stage 1 while it writes
-    the rows when the variable is set for the whole run (SpecialRowsPartition.peaks), read back from the rows otherwise."""
+    The default since round 6 (BASELINE config 3 on one MI355X: stage 2 15.8 s as a chain, 7.8 s this way, the same
+    alignment.00.txt and crosspoint_04.00 -- profiles/r06_native_pipeline_c3_48Mx46M_stage2_guessed.json);
+    stage2(speculate=False) or MI355SW_STAGE2_SPECULATE=0 walks the plain chain.  The row maxima are recorded by stage 1 while
+    it writes the rows (SpecialRowsPartition.peaks), read back from the rows where they were not."""
 
     def __init__(self, mgr, area, part1, cp, col_reader, len_v, len_h, alignment_start):
         self.area = area
@@ -233,10 +240,10 @@ def stage2(aligner, seq0, seq1, work, alignment_start=AT_ANYWHERE, sra_limit=0, 
     with sra_limit > 0, its special rows there).  seq0 / seq1: the whole sequences; `bounds` = (i0, j0, i1, j1) the
     part --trim selected for stage 1 (only its origin matters here: where a global alignment must begin).  Returns {"crosspoints": [(type, i, j, score), ...] as written to
     crosspoint_02.NN, "end": the last crosspoint in ORIGINAL coordinates, "partitions", "seconds"}.
-    speculate: sweeps from guessed crosspoints side by side (_Speculation); None = MI355SW_STAGE2_SPECULATE."""
+    speculate: sweeps from guessed crosspoints side by side (_Speculation); None = on unless MI355SW_STAGE2_SPECULATE=0."""
     t_start = time.time()
     if speculate is None:
-        speculate = bool(os.environ.get("MI355SW_STAGE2_SPECULATE"))
+        speculate = speculation_default()
     guessed = {"sweeps": 0, "accepted": 0, "discarded": 0}
     s0, s1 = _as_u8(seq0), _as_u8(seq1)
     m, n = len(s0), len(s1)

@@ -748,8 +748,9 @@ def test_stage2_from_guessed_crosspoints_leaves_the_same_files(name, pair, bh, b
         work = str(tmp_path / mode)
         al = (Batched if mode == "guessed_batched" else SerialBlockAligner)(bh, bw)
         areas = {}
-        if mode == "recorded_peaks":                 # the variable set for the whole run: stage 1 records the maxima as it writes
-            monkeypatch.setenv("MI355SW_STAGE2_SPECULATE", "1")
+        # (round 6: guessing is the default and stage 1 records the row maxima as it writes; with the variable at 0 it does not,
+        #  and a stage 2 that is asked to guess all the same reads them back from the rows)
+        monkeypatch.setenv("MI355SW_STAGE2_SPECULATE", "1" if mode == "recorded_peaks" else "0")
         if mode == "all_guesses_wrong":
             real = sra.SpecialRowsPartition.row_peak
 

@@ -58,6 +58,8 @@ def main():
         res["returncode"] = p.returncode
         log = p.stdout.decode(errors="replace")
         res["log_tail"] = log[-1500:]
+        if os.environ.get("DROPIN_LOG"):          # the whole log (e.g. with --engine-verbosity=2: one line per mi355sw_align_partition job)
+            open(os.environ["DROPIN_LOG"], "w").write(log)
         # special rows stay on disk (gigabytes at these sizes): count the files, read everything else
         sra = os.path.join(work, "special_rows")
         n_rows = sum(len([f for f in fs if len(f) == 8]) for _, _, fs in os.walk(sra)) if os.path.isdir(sra) else 0

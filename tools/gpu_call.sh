@@ -12,7 +12,7 @@
 #   rehearse       the N > 1 path of bench.py on the one GPU through every transport and recurrence (self-launched)
 #   ab:M,N[,R]     a related M x N pair: unpruned, pruned with the window, pruned without it (tools/window_probe.py)
 #   c3             C3's stage 1 at full size, pruned, against the recorded unpruned run (tools/scale_run.py c3pruned) -> scale_c3pruned.json
-#   native[:spec]  BASELINE config 3 (48 M x 46 M) through the native pipeline, stages 1-6 (spec: MI355SW_STAGE2_SPECULATE=1) -> native_pipeline_c3[_spec].json
+#   native[:chain] BASELINE config 3 (48 M x 46 M) through the native pipeline, stages 1-6 (chain: MI355SW_STAGE2_SPECULATE=0, stage 2 as the plain chain) -> native_pipeline_c3[_spec].json
 #   dropin[:OPTS]  ... through MASA-Core's own stages on the engine (tools/dropin_scale.py, --gpu-stage4 OPTS) -> dropin_pipeline_c3.json
 #   pmc            rocprofv3 kernel statistics + PMC passes of the default bench command (tools/pmc_collect.sh TAG)
 #   py:SCRIPT,ARGS python3 tools/SCRIPT ARGS... (comma separated)
@@ -84,14 +84,15 @@ print('rehearsal $t rc=$r: value %.0f comm %s launcher %s pruned %.3f best %s ke
         timeout 1500 python3 tools/scale_run.py c3pruned $out/scale_c3pruned.json > $out/scale_c3.log 2>&1; rc=$?
         tail -5 $out/scale_c3.log ;;
     native)       # BASELINE config 3 through the native pipeline (stages 1-6); native:spec = stage 2 from guessed crosspoints
-        sfx=""; [ "$arg" = "spec" ] && { export MI355SW_STAGE2_SPECULATE=1; sfx="_spec"; }
+        sfx=""; [ "$arg" = "spec" ] && { export MI355SW_STAGE2_SPECULATE=1; sfx="_spec"; }; [ "$arg" = "chain" ] && { export MI355SW_STAGE2_SPECULATE=0; sfx="_chain"; }
         timeout 1500 python3 tools/native_pipeline_run.py 48000000 46000000 25769803776 $out/native_pipeline_c3$sfx.json 5 > $out/native_c3$sfx.log 2>&1; rc=$?
         unset MI355SW_STAGE2_SPECULATE
         python3 -c "
 import json; d=json.load(open('$out/native_pipeline_c3$sfx.json'))
 print('native C3$sfx: total %.1f s, stages %s, alignment %s crosspoint_04 %s' % (d['total_seconds'], {k: round(v, 2) for k, v in d['seconds'].items()}, d['alignment_sha256'][:8], d['crosspoint_04_sha256'][:8]))" || tail -5 $out/native_c3$sfx.log ;;
     dropin)       # ... and through MASA-Core's own stages on the engine (oracle/_ref/masa_mi355)
-        DROPIN_EXTRA="--gpu-stage4 $arg" timeout 1500 python3 tools/dropin_scale.py 48000000 46000000 24G $out/dropin_pipeline_c3.json > $out/dropin_c3.log 2>&1; rc=$?
+        DROPIN_LOG=$out/dropin_c3_full.log DROPIN_EXTRA="--gpu-stage4 $arg" timeout 1500 python3 tools/dropin_scale.py 48000000 46000000 24G $out/dropin_pipeline_c3.json > $out/dropin_c3.log 2>&1; rc=$?
+        grep "job " $out/dropin_c3_full.log | awk 'NR % 200 == 1' | head -40 > $out/dropin_c3_jobs_sample.log; rm -f $out/dropin_c3_full.log
         python3 -c "
 import json; d=json.load(open('$out/dropin_pipeline_c3.json'))
 print('drop-in C3: wall %.1f s, alignment %s crosspoint_04 %s, stage totals %s' % (d['wall_s'], d['alignment_sha256'][:8], d['crosspoint_04_sha256'][:8], {k: v.get('TOTAL', v.get('Total')) for k, v in d.items() if k.startswith('stage') and isinstance(v, dict)}))" || tail -5 $out/dropin_c3.log ;;

@@ -57,7 +57,7 @@ def main():
            "crosspoints": {str(k): v for k, v in out["crosspoints"].items()},
            "stage1_gcups": out["stage1"]["gcups"], "stage1_kernel_ms": out["stage1"].get("kernel_ms"),
            "stage1_strip_rows": out["stage1"].get("strip_rows"), "stage1_pruned_fraction": out["stage1"].get("pruned_cells", 0) / float(m) / n,
-           "stage3_rounds": out.get("stage3", {}).get("rounds"),
+           "stage3_rounds": out.get("stage3", {}).get("rounds"), "stage2_speculation": out.get("stage2", {}).get("speculation"),
            "stage4": out.get("stage4"), "alignment_score": out["alignment"].raw_score if out["alignment"] else None,
            "text_bytes": len(out["text"]) if out["text"] else 0}
     # the same digests tools/dropin_scale.py records for MASA-Core's own stages on the engine: equal = the same files
