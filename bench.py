@@ -246,22 +246,25 @@ def launch_check(args):
     if backend == "nccl":
         torch.cuda.set_device(local_rank)
         device = torch.device("cuda", local_rank)
-    if world > 1:
+    # (a forced "nccl" with ONE rank still makes the group: RCCL initialised and one all_reduce through it on a one-GPU box)
+    grouped = world > 1 or os.environ.get("MI355SW_LAUNCH_CHECK_BACKEND") == "nccl"
+    if grouped:
+        os.environ.setdefault("MASTER_PORT", "29533")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)     # the call main() makes
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
     t = torch.tensor([rank + 1], dtype=torch.int64, device=device)
-    if world > 1:
+    if grouped:
         dist.all_reduce(t)
     if args.launch_check_sleep > 0:
         time.sleep(args.launch_check_sleep)
     if rank == 0:
         print(json.dumps({"launch_check": True, "world": world, "gpus": args.gpus, "sum_of_ranks": int(t.item()),
-                          "backend": backend if world > 1 else "none", "devices_visible": torch.cuda.device_count(),
+                          "backend": backend if grouped else "none", "devices_visible": torch.cuda.device_count(),
                           "launcher": os.environ.get("MI355SW_BENCH_LAUNCHER", "external"),
                           "master": "%s:%s" % (os.environ.get("MASTER_ADDR"), os.environ.get("MASTER_PORT"))}), flush=True)
-    if world > 1:
+    if grouped:
         dist.barrier()
         dist.destroy_process_group()
     return 0

@@ -9,6 +9,7 @@
 #                  bound a run's TIME may fail next to five other processes on the GPU, hence the second, serial pass
 #   bench          python3 bench.py (the driver's N = 1 command) -> bench.json
 #   selflaunch:N   MI355SW_BENCH_REHEARSAL=1 python3 bench.py --gpus N --size 300000  (bench.py starts its own ranks; all on cuda:0)
+#   launchcheck    bench.py --launch-check: 2 ranks (gloo on a one-GPU box), then the nccl (= RCCL) backend with one rank on the GPU
 #   rehearse       the N > 1 path of bench.py on the one GPU through every transport and recurrence (self-launched)
 #   ab:M,N[,R]     a related M x N pair: unpruned, pruned with the window, pruned without it (tools/window_probe.py)
 #   c3             C3's stage 1 at full size, pruned, against the recorded unpruned run (tools/scale_run.py c3pruned) -> scale_c3pruned.json
@@ -60,7 +61,15 @@ PY
         python3 -c "
 import json
 d=json.loads(open('$out/selflaunch_$arg.json').read().strip().splitlines()[-1]); c=d['config']
-print('self-launched N=%d: value %.0f comm %s launcher %s xgmi %s note %s best %s' % (d['n_gpus'], d['value'], c['comm'], c['launcher'], c['xgmi'], c['comm_note'], d['best']))" ;;
+print('self-launched N=%d: value %.0f comm %s launcher %s xgmi %s note %s best %s' % (d['n_gpus'], d['value'], c['comm'], c['launcher'], c['xgmi'], c['comm_note'], d['best']))
+for k in ('c4_half', 'c4_full', 'c5_full'):
+    if k in d:
+        v = d[k]; print(' ', k, {kk: (round(vv, 2) if isinstance(vv, float) else vv) for kk, vv in v.items() if not isinstance(vv, (dict, list))}, v.get('check'))" ;;
+    launchcheck)  # --launch-check on the box: N ranks over gloo (one GPU: fewer devices than ranks), then RCCL itself with the one rank a one-GPU box allows
+        python3 bench.py --gpus 2 --launch-check > $out/launch_check_n2.json 2> $out/launch_check_n2.err; rc=$?
+        MI355SW_LAUNCH_CHECK_BACKEND=nccl timeout 600 python3 bench.py --gpus 1 --launch-check > $out/launch_check_nccl_one_rank.json 2> $out/launch_check_nccl_one_rank.err; r2=$?
+        [ $r2 -ne 0 ] && rc=$r2
+        cat $out/launch_check_n2.json $out/launch_check_nccl_one_rank.json; tail -3 $out/launch_check_nccl_one_rank.err ;;
     rehearse)
         rc=0
         run() { n=$1; t=$2; shift 2
