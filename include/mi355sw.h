@@ -118,6 +118,13 @@ typedef struct {
                                                on the device (InitialCellsReader is a function of the position).  The default became
                                                possible with the stop every strip sees at once (KernelArgs::stop_word): with all rows there
                                                from the start hundreds of strips are in flight when the manager says stop (A/B, tests) */
+#define MI355SW_F_DETERMINISTIC_PRUNE 16384 /* reproducible special rows under block pruning: a strip tests against the bound as it stood a fixed number
+                                               of strips above it (plus its own finds) instead of against the newest value any wavefront has
+                                               published -- WHICH slabs go is then a function of the input, as in the reference, whose pruning
+                                               window is set on the host between two diagonals (BlockPruningDiagonal.cpp:109-152).  Two runs, or an
+                                               interrupted and resumed run and an uninterrupted one, leave the same special rows.  Costs nothing
+                                               where the bound starts from the seed; a bound that grows with the sweep arrives one round of
+                                               wavefronts later.  A stream on its own only (the bands of a chain share their finds as they arrive) */
 #define MI355SW_F_NO_HOST_COUNTER 512       /* the kernel does not mirror its strip counter into host memory (measurements) */
 #define MI355SW_V_MESSAGES 1                /* one line per noteworthy event (overflow reruns, the diagonal seed, ...) */
 #define MI355SW_V_JOBS 2                    /* timing of every mi355sw_align_partition job */

@@ -9,6 +9,7 @@
 namespace mi355sw {
 
 enum { CHUNK = 64 };   // bus columns staged per hand-off (one per lane)
+enum { DET_UNSET = (int) 0x80000000 };   // KernelArgs::det_prefix entry that has not been written yet
 
 // M/libmasa/IManager.hpp:36-47
 enum { INIT_WITH_ZEROES = 0, INIT_WITH_GAPS = 1, INIT_WITH_CUSTOM_DATA = 2, INIT_WITH_GAPS_OPENED = 3 };
@@ -86,6 +87,18 @@ struct KernelArgs {
                                  // columns strip s left unwritten at win[2(s+1)] (see WIN_RETIRED in sw_kernel_pk16.inc) -- or nullptr (no window)
     int band_c0, band_slope_q16, band_w;   // band mode (pruning kernels with a window; band_w > 0): only columns within band_w of
                                  // the line  column = band_c0 + row * band_slope_q16 / 65536  (row relative to the partition) are computed
+    // ---- reproducible pruning (MI355SW_F_DETERMINISTIC_PRUNE; nullptr = off) ----
+    // WHICH slabs a pruning run skips depends on what the running best was when a wavefront looked at it -- with gbest, on
+    // timing: two runs of one input leave different lower bounds off the optimal paths in their special rows.  The reference
+    // decides its pruning window on the host between two external diagonals (BlockPruningDiagonal::updatePruningWindow,
+    // BlockPruningDiagonal.cpp:109-152): a function of the input.  In this mode strip s tests against
+    //   det_prefix[max(0, s - det_lag)] = max(what the run started from, what strips 0 .. s - det_lag - 1 found)
+    // -- final when strip s starts (completion is ordered, at most det_lag strips are ever in flight) -- and against what IT
+    // has found so far, left to right.  det_news[s]: what strip s found (T domain), folded into the prefix by
+    // complete_strip_common.  Entries not yet written hold DET_UNSET; a reader waits for them (it never has to, see above).
+    int* det_prefix;             // [strips + 1]
+    int* det_news;               // [strips]
+    int det_lag;
     const int* gbest_in;         // where the strips READ the running best from: gbest itself, or a word that stays at -INF
                                  // when every strip record must be that strip's own exact best (block scores) instead
                                  // of "nothing below what is already known elsewhere"
@@ -223,6 +236,12 @@ static __device__ __attribute__((noinline, unused)) void complete_strip_common(c
             // low byte: the code; above it, for an overflow report of the packed kernel, its causes (error_flag[1])
             const int why = __hip_atomic_load(a->error_flag + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(a->host_error, err | (why << 8), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        if (!gone && a->det_prefix != nullptr) {
+            // (ordered section: prefix[s] is final; release before the counter below lets anybody count on prefix[s + 1])
+            const int before = __hip_atomic_load(&a->det_prefix[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int mine = __hip_atomic_load(&a->det_news[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&a->det_prefix[s + 1], max(before, mine), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         }
         if (!gone) {
             if (a->peer_ready != nullptr && err == 0 &&

@@ -1,0 +1,86 @@
+"""GPU (-m gpu): reproducible pruning (MI355SW_F_DETERMINISTIC_PRUNE).  The reference decides which blocks a diagonal may skip
+on the host, between two external diagonals (BlockPruningDiagonal::updatePruningWindow, M/libmasa/pruning/BlockPruningDiagonal.cpp:
+109-152): its special rows are a function of the input.  The engine's strips test against a device-wide running best, so WHICH
+slabs go depends on when a wavefront looked at it -- the best cell never does, the lower bounds left off the optimal paths do.
+In this mode a strip tests against the bound as it stood a fixed number of strips above it plus its own finds
+(KernelArgs::det_prefix): two runs leave the same bytes."""
+import hashlib
+
+import numpy as np
+import pytest
+
+from test_gpu_bound import _stream
+
+pytestmark = pytest.mark.gpu
+
+
+def _digest(res):
+    h = hashlib.sha256()
+    for dp in sorted(res["rows"]):
+        h.update(np.ascontiguousarray(res["rows"][dp], dtype=np.int32).tobytes())
+    h.update(np.ascontiguousarray(res["last_row"], dtype=np.int32).tobytes())
+    h.update(np.ascontiguousarray(res["last_col"], dtype=np.int32).tobytes())
+    return h.hexdigest()
+
+
+@pytest.mark.parametrize("kind,m,n,R", [
+    ("local", 2600000, 2300000, 0),        # the bound grows with the sweep (no seed below 8 Mi rows): several rounds of wavefronts
+    ("local", 400000, 380000, 4),          # 1563 strips of 256 rows
+    ("global", 1500000, 1460000, 8),       # a running LOWER bound of H[m][n]
+])
+def test_two_runs_leave_the_same_special_rows(pkg, kind, m, n, R):
+    from masa_cudalign_amd.engine import SMITH_WATERMAN, NEEDLEMAN_WUNSCH, F_DETERMINISTIC_PRUNE
+    s0, s1 = pkg.seqgen.related_pair(m, n, cfg=611)
+    rec = SMITH_WATERMAN if kind == "local" else NEEDLEMAN_WUNSCH
+    interval = max(8192, m // 24)
+    runs = []
+    for flags in (F_DETERMINISTIC_PRUNE, F_DETERMINISTIC_PRUNE, 0):
+        al = pkg.MI355Aligner(device=0, rows_per_lane=R, flags=flags)
+        try:
+            al.setSequences(s0, s1)
+            runs.append(_stream(pkg, al, m, n, rec, None, interval=interval))
+        finally:
+            al.close()
+    al = pkg.MI355Aligner(device=0, rows_per_lane=R)
+    try:
+        al.setSequences(s0, s1)
+        plain = _stream(pkg, al, m, n, rec, None, interval=interval, prune=False)
+    finally:
+        al.close()
+    a, b, free = runs
+    assert a["stats"]["pruned_cells"] > 0.2 * m * n                  # it prunes ...
+    assert a["stats"]["pruned_cells"] == b["stats"]["pruned_cells"]   # ... the same slabs in both runs
+    assert _digest(a) == _digest(b)                                   # the same bytes: special rows, last row, last column
+    assert sorted(a["rows"]) == sorted(plain["rows"]) and len(a["rows"]) >= 8
+    # and they are what a pruning run may leave: the answer exact, everything else a lower bound of the unpruned run
+    if kind == "local":
+        assert a["best"] == plain["best"] == free["best"]
+    else:
+        assert int(a["last_row"][-1, 0]) == int(plain["last_row"][-1, 0]) == int(free["last_row"][-1, 0])
+    for dp in plain["rows"]:
+        assert np.all(a["rows"][dp] <= plain["rows"][dp]), dp
+    assert np.all(a["last_row"] <= plain["last_row"]) and np.all(a["last_col"] <= plain["last_col"])
+    # the price: the bound reaches a strip one round of wavefronts later than it could
+    print("%s %d x %d: pruned %.3f (reproducible) / %.3f (running best), kernel %.1f / %.1f ms" % (
+        kind, m, n, a["stats"]["pruned_cells"] / float(m) / n, free["stats"]["pruned_cells"] / float(m) / n,
+        a["stats"]["kernel_ms"], free["stats"]["kernel_ms"]))
+
+
+def test_a_seeded_run_is_reproducible_at_no_cost(pkg):
+    """9 M x 8.6 M: the bound starts from the seed (= the answer on this kind of pair) and never moves -- the mode costs nothing"""
+    from masa_cudalign_amd.engine import SMITH_WATERMAN, F_DETERMINISTIC_PRUNE
+    m, n = 9000000, 8600000
+    s0, s1 = pkg.seqgen.related_pair(m, n, cfg=612)
+    out = []
+    for flags in (F_DETERMINISTIC_PRUNE, F_DETERMINISTIC_PRUNE, 0):
+        al = pkg.MI355Aligner(device=0, flags=flags)
+        try:
+            al.setSequences(s0, s1)
+            out.append(_stream(pkg, al, m, n, SMITH_WATERMAN, None, interval=1 << 20))
+        finally:
+            al.close()
+    a, b, free = out
+    assert _digest(a) == _digest(b) and a["best"] == b["best"] == free["best"]
+    assert a["stats"]["pruned_cells"] == b["stats"]["pruned_cells"] > 0.5 * m * n
+    print("seeded 9 M x 8.6 M: kernel %.0f / %.0f ms reproducible, %.0f ms running best" % (a["stats"]["kernel_ms"], b["stats"]["kernel_ms"], free["stats"]["kernel_ms"]))
+    assert a["stats"]["kernel_ms"] < 1.08 * free["stats"]["kernel_ms"]
