@@ -34,7 +34,7 @@ def test_a_stop_ends_a_thousand_strips_within_a_millisecond_or_so(pkg, recurrenc
     print("stop latency %s: %s ms with %d wavefronts, strips of %d rows" % (recurrence, [round(r["stop_ms"], 3) for r in runs], runs[0]["waves"], runs[0]["strip_rows"]))
     assert runs[0]["waves"] >= 1000 and runs[0]["strips"] > 3 * runs[0]["waves"]
     assert all(r["rows_at_stop"] < m // 2 for r in runs)                   # the stop came in mid-flight ...
-    assert all(r["kernel_ms"] < 400 for r in runs)                         # ... and the rest of the partition (1 s of sweeps) never ran
+    assert all(r["processed_cells"] < 0.5 * m * n for r in runs)           # ... and most of the partition never ran (what was complete or in flight)
     assert best < 5.0, runs
 
 

@@ -78,6 +78,9 @@ def main():
             if pts:
                 res["crosspoints_%d" % st] = {"count": len(pts), "first": list(pts[0]), "last": list(pts[-1])}
         import hashlib
+        for st in (2, 3):
+            if out.get("crosspoints_%d" % st):
+                res["crosspoint_%02d_sha256" % st] = hashlib.sha256(repr([tuple(p) for p in out["crosspoints_%d" % st]]).encode()).hexdigest()
         if "crosspoints_4_txt" in out:
             res["crosspoint_04_sha256"] = hashlib.sha256(out["crosspoints_4_txt"]).hexdigest()
         gl = [ln for ln in out.get("statistics", {}).get("statistics_04.00", "").splitlines() if ln.startswith("GPU STAGE 4")]

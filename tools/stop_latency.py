@@ -40,7 +40,7 @@ def measure(pkg, al, m, n, stop, sw=False):
     al.streamEnd()
     st = al.getStatistics()
     return dict(rows_at_stop=int(rows), stop_ms=(t1 - t0) * 1e3, kernel_ms=st["kernel_ms"], strip_rows=st["strip_rows"],
-                waves=st["waves"], strips=st["strips"], kernel=st["kernel"])
+                waves=st["waves"], strips=st["strips"], kernel=st["kernel"], processed_cells=st["processed_cells"])
 
 
 def main():
