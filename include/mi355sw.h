@@ -125,6 +125,8 @@ typedef struct {
                                                interrupted and resumed run and an uninterrupted one, leave the same special rows.  Costs nothing
                                                where the bound starts from the seed; a bound that grows with the sweep arrives one round of
                                                wavefronts later.  A stream on its own only (the bands of a chain share their finds as they arrive) */
+#define MI355SW_F_NO_GOAL_SWEEP_HEIGHTS 32768 /* mi355sw_align_partition leaves the strip height of a sweep that looks goal-stopped (MASA-Core's stages 2 and 3,
+                                               see AlignJob::begin) to the cost model like any other partition's (A/B measurements) */
 #define MI355SW_F_NO_HOST_COUNTER 512       /* the kernel does not mirror its strip counter into host memory (measurements) */
 #define MI355SW_V_MESSAGES 1                /* one line per noteworthy event (overflow reruns, the diagonal seed, ...) */
 #define MI355SW_V_JOBS 2                    /* timing of every mi355sw_align_partition job */

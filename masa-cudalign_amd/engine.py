@@ -28,6 +28,7 @@ F_FORCE_GENERIC_COMPARE, F_FORCE_INT32, F_NO_DIAGONAL_SEED, F_NO_SEED_PASS, F_NO
 F_TWO_PHASE, F_NO_MIXED, F_NO_SHARED_BEST, F_NO_BATCH, F_NO_HOST_COUNTER, F_NO_WINDOW, F_STAIRCASE_SEED = 32, 64, 128, 256, 512, 1024, 2048
 F_GENERATE_GAP_COLUMNS = 4096      # (ABI 7's opt-in; the default since ABI 8, accepted and ignored)
 F_DETERMINISTIC_PRUNE = 16384      # reproducible special rows under block pruning
+F_NO_GOAL_SWEEP_HEIGHTS = 32768
 F_STREAM_GAP_COLUMNS = 8192        # gap-initialised first columns taken from the manager's stream instead of made on the device
 V_MESSAGES, V_JOBS, V_SEED_TILES, V_BATCH, V_DEBUG_WORDS = 1, 2, 4, 8, 16
 
@@ -37,7 +38,8 @@ V_MESSAGES, V_JOBS, V_SEED_TILES, V_BATCH, V_DEBUG_WORDS = 1, 2, 4, 8, 16
 _ENV_FLAGS = {"MI355SW_NO_DIAGONAL_SEED": F_NO_DIAGONAL_SEED, "MI355SW_NOSEED": F_NO_SEED_PASS, "MI355SW_NO_PRUNE_PROBE": F_NO_PRUNE_PROBE,
               "MI355SW_TWO_PHASE": F_TWO_PHASE, "MI355SW_NO_MIXED": F_NO_MIXED, "MI355SW_NO_SHARED_BEST": F_NO_SHARED_BEST,
               "MI355SW_NO_BATCH": F_NO_BATCH, "MI355SW_NOHOST": F_NO_HOST_COUNTER, "MI355SW_NO_WINDOW": F_NO_WINDOW, "MI355SW_STAIRCASE_SEED": F_STAIRCASE_SEED,
-              "MI355SW_STREAM_GAP_COLUMNS": F_STREAM_GAP_COLUMNS, "MI355SW_DETERMINISTIC_PRUNE": F_DETERMINISTIC_PRUNE}
+              "MI355SW_STREAM_GAP_COLUMNS": F_STREAM_GAP_COLUMNS, "MI355SW_DETERMINISTIC_PRUNE": F_DETERMINISTIC_PRUNE,
+              "MI355SW_NO_GOAL_SWEEP_HEIGHTS": F_NO_GOAL_SWEEP_HEIGHTS}
 _ENV_VERBOSITY = {"MI355SW_VERBOSE": V_MESSAGES, "MI355SW_VERBOSE_JOBS": V_JOBS, "MI355SW_VERBOSE_TILES": V_SEED_TILES,
                   "MI355SW_BATCH_DEBUG": V_BATCH, "MI355SW_DEBUG": V_DEBUG_WORDS}
 

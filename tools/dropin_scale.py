@@ -65,6 +65,12 @@ def main():
         n_rows = sum(len([f for f in fs if len(f) == 8]) for _, _, fs in os.walk(sra)) if os.path.isdir(sra) else 0
         sra_bytes = sum(os.path.getsize(os.path.join(d, f)) for d, _, fs in os.walk(sra) for f in fs) if os.path.isdir(sra) else 0
         shutil.rmtree(sra, ignore_errors=True)
+        if os.environ.get("DROPIN_KEEP_CROSSPOINTS"):     # crosspoint_02 / _03 of this run, for a line-by-line comparison of two runs
+            os.makedirs(os.environ["DROPIN_KEEP_CROSSPOINTS"], exist_ok=True)
+            for st in (2, 3):
+                fn = os.path.join(work, "crosspoints", "crosspoint_%02d.00" % st)
+                if os.path.exists(fn):
+                    shutil.copy(fn, os.path.join(os.environ["DROPIN_KEEP_CROSSPOINTS"], "crosspoint_%02d.00" % st))
         out = read_ref_work(work, log=log)
         res["best"] = list(out["best"]) if out["best"] else None
         for st in range(1, 7):
