@@ -761,6 +761,8 @@ def run_full_config(fc, pkg, torch, dist, make_dist, p2p_group, world, rank, loc
                 check["not_below_the_bound_the_pruning_started_from"] = False
                 out["bound_error"] = str(e)
             exp = fc.get("expect")
+            if exp is not None and getattr(pkg.seqgen, "GENERATOR_VERSION", None) != RECORDED_FOR_GENERATOR:
+                exp = None                                   # recorded for another generator: compare with one band instead
             if exp is not None:
                 check["equals_the_recorded_one_gpu_run"] = (best[0] + 1, best[1] + 1, best[2]) == (exp["i"], exp["j"], exp["score"])
                 out["expect"] = exp
@@ -899,7 +901,9 @@ def c3_shape(pkg, device):
 
 # C3's stage 1 without pruning, swept once on this engine family (builder-side, 6 minutes of GPU: tools/scale_run.py c3 ->
 # profiles/r04_scale_c3_48Mx46M.json "unpruned"): the best cell a pruned run of the same pair must report (0-based i, j)
+# (recorded for seqgen.GENERATOR_VERSION 1: with another generator the comparison is skipped, not failed -- ADVICE round 5)
 C3_RECORDED_UNPRUNED_BEST = (45999788, 45999999, 35906671)
+RECORDED_FOR_GENERATOR = 1
 
 
 def c3_full(pkg, device):
@@ -952,7 +956,8 @@ def c3_full(pkg, device):
     out["check"] = {"pruned_rows_are_lower_bounds_of_the_unpruned_band": bool(lower), "rows_crossed_inside_the_band": len(crossed),
                     "row_maxima_equal_where_the_alignment_crosses_the_band": bool(same_max and len(crossed) >= 1),
                     "row_maxima_above_the_best_cell_within_reach_of_it": bool(len(above) >= 10 and within),
-                    "best_cell_is_the_recorded_unpruned_sweeps": tuple(best) == C3_RECORDED_UNPRUNED_BEST,
+                    "best_cell_is_the_recorded_unpruned_sweeps": (tuple(best) == C3_RECORDED_UNPRUNED_BEST)
+                    if getattr(pkg.seqgen, "GENERATOR_VERSION", None) == RECORDED_FOR_GENERATOR else "skipped: another sequence generator",
                     "no_restart": br.restarts == 0}
     out["check"]["ok"] = all(v for v in out["check"].values() if isinstance(v, bool))
     return out

@@ -78,6 +78,9 @@ def mutate_dna(seq0, seed, p_sub=0.02, p_indel=0.002, indel_mean=3.0, inversion=
 # seeds fixed per BASELINE.md section 2
 SEED0 = 0xC0FFEE00
 SEED1 = 0xBADC0DE0
+# identity of the generator: recorded results (bench.py's expected best cells, the digests under profiles/) name the pairs they
+# belong to by (kind, m, n, cfg) AND this number; whoever changes what a (kind, m, n, cfg) produces raises it
+GENERATOR_VERSION = 1
 
 
 def unrelated_pair(m, n, cfg=0):
