@@ -161,6 +161,15 @@ def main():
     res["check"] = {"oracle_window": "600x600 ending at the reported cell", "oracle_best_in_window": int(ref["best"][2]),
                     "oracle_H_at_cell": int(ref["last_row"][-1][0]),
                     "ok": bool(ref["best"][2] == best[2] and int(ref["last_row"][-1][0]) == best[2])}
+    # ... and the cell round 2's kernels reported for the same pair (profiles/r02_northstar_228Mx228M.json), where that record is at hand
+    try:
+        old = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r02_northstar_228Mx228M.json")))
+        if (m, n) == (228000000, 228000000) and getattr(pkg.seqgen, "GENERATOR_VERSION", 1) == 1:
+            res["check"]["equals_the_cell_of_round_2s_run"] = res["best"] == old["best"]
+            res["check"]["ok"] = res["check"]["ok"] and res["check"]["equals_the_cell_of_round_2s_run"]
+    except (OSError, ValueError, KeyError):
+        pass
+    res["library_build_id"] = pkg.engine.library_build_id()
     print(json.dumps({k: v for k, v in res.items() if k != "band"}), flush=True)
     if outfn:
         json.dump(res, open(outfn, "w"), indent=1)
