@@ -30,7 +30,10 @@ def _same(a, b):
         assert np.array_equal(np.concatenate(a.special_rows[k]), np.concatenate(b.special_rows[k])), k
 
 
-def test_batched_partitions_equal_single_calls(pkg, oracle):
+@pytest.mark.parametrize("R", [4, 8, 16])
+def test_batched_partitions_equal_single_calls(pkg, oracle, R):
+    """R = the strip height of the batch's one launch (mi355sw_config.batch_rows_per_lane: 256 rows for stage 3's small
+    partitions, 512 / 1024 -- round 6, sw_batch_kernel_pk16<8,...> -- for batches of tall ones: stage 2's guessed sweeps)"""
     m, n = 60000, 50000
     s0, s1 = pkg.seqgen.related_pair(m, n, cfg=71)
     rng = np.random.RandomState(5)
@@ -42,19 +45,20 @@ def test_batched_partitions_equal_single_calls(pkg, oracle):
         kinds.append(("nw", "semi", "sw")[k % 3])
     parts.append(pkg.Partition(0, 0, 1, 1)); kinds.append("nw")                   # the smallest partition there is
     parts.append(pkg.Partition(100, 100, 100, 4000)); kinds.append("nw")          # spans no cells: skipped (AlignerManager.cpp:96-99)
-    al = pkg.MI355Aligner(device=0, rows_per_lane=4)
+    al = pkg.MI355Aligner(device=0, rows_per_lane=R)
     try:
         al.setSequences(s0, s1)
         single = _managers(pkg, parts, kinds)
         for p, mg in zip(parts, single):
             al.alignPartition(p, mg)
         batch = _managers(pkg, parts, kinds)
-        al.alignPartitions(parts, batch)
+        al.alignPartitions(parts, batch, **({} if R == 4 else {"rows_per_lane": R}))
         st = al.getStatistics()
         al.unsetSequences()
     finally:
         al.close()
-    assert st["kernel_launches"] >= 1 and st["strip_rows"] == 256
+    assert st["kernel_launches"] >= 1 and st["strip_rows"] == 64 * R
+    assert st["kernel"].startswith("sw_batch_kernel_pk16<%d," % (R // 2))
     for k, (a, b) in enumerate(zip(single, batch)):
         if parts[k].getHeight() == 0 or parts[k].getWidth() == 0:
             continue

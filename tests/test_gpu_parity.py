@@ -394,10 +394,18 @@ def test_block_pruning_keeps_the_canonical_best(pkg, oracle):
         assert out[True][1] > 0.15 * m * n                       # a sizeable part of the matrix was skipped
         assert out[True][1] + al.getStatistics()["processed_cells"] == m * n
         mgp = out[True][2]
+        crossed = 0
         for i in sorted(mgp.special_rows):
             got, want = mgp.specialRow(i)[:, 0], want_rows[i][:, 0]
             assert (got <= want).all() and (got[1:] >= 0).all()
-            assert got.max() == want.max() and int(got.argmax()) == int(want.argmax())
+            # a row the OPTIMAL path crosses (rows above the best cell) keeps its maximum: it lies on that path.  Below the best
+            # cell a row's maximum belongs to some other alignment -- here one that runs into the last column 20 000 below the
+            # optimum -- and may go like anything else that cannot reach the best (round 6: the chunks at the end of a row are
+            # asked the skip test too; they used to be computed whatever the bound said)
+            if i <= ref["best"][0]:
+                assert got.max() == want.max() and int(got.argmax()) == int(want.argmax())
+                crossed += 1
+        assert crossed >= 4
     finally:
         al.close()
 
