@@ -26,6 +26,10 @@ from . import sra as sra_mod
 
 MATCH_SCORE = 1
 MIN_ROW_DISTANCE = 128          # sw_stage2.cpp:420: special rows nearer than this to the crosspoint are skipped
+# a sweep from a GUESSED crosspoint is given up this many rows + twice its width down its last column, and its partition ends
+# GUESS_PARTITION_SLACK rows below that (the engine hands the column over in chunks of up to 16 strips)
+GUESS_CAP_SLACK = 4096
+GUESS_PARTITION_SLACK = 16384
 
 
 def speculation_default():
@@ -131,7 +135,8 @@ class _Speculation:
     plain walk would have made: same borders, same goal, same special rows saved, same hit.  A guess that is off (the path
     crosses the row inside a gap, or one of several co-optimal paths is met first) costs its sweep, which is thrown away
     (SpecialRowsArea.discard_partition), and the walk makes that one step the plain way.  The files of the stage do not
-    change.  No counterpart in the reference (its stage 2 is the plain chain, sw_stage2.cpp:387-441).
+    change.  The special rows an accepted sweep saves are the rows the chain's sweep would have saved (both are cut back to the
+    crosspoint), so the area holds what the budget was planned for plus the rows of the sweeps still to be thrown away.  No counterpart in the reference (its stage 2 is the plain chain, sw_stage2.cpp:387-441).
 
     The default since round 6 (BASELINE config 3 on one MI355X: stage 2 15.8 s as a chain, 7.8 s this way, the same
     alignment.00.txt and crosspoint_04.00 -- profiles/r06_native_pipeline_c3_48Mx46M_stage2_guessed.json);
@@ -180,8 +185,8 @@ class _Speculation:
                 # need not be taller than that: the engine sizes its buffers -- first column, special rows of its own -- by
                 # the partition's height, and dozens of sweeps as tall as what is left of the sequence (C3: 22 M rows, 15 GB of
                 # special-row room each) do not fit side by side.  The rows above the cut do not depend on what lies below.
-                cap = 2 * (c1.j - c0.j) + 4096
-                c1p = Crosspoint(min(c1.i, c0.i + cap + 16384), c1.j) if guess else c1
+                cap = 2 * (c1.j - c0.j) + GUESS_CAP_SLACK
+                c1p = Crosspoint(min(c1.i, c0.i + cap + GUESS_PARTITION_SLACK), c1.j) if guess else c1
                 m = _GuessManager.of(mgr, cap) if guess else mgr.clone()
                 row = sra_mod.SpecialRowReader(part1, ids[t])
                 row.seek(abs(c0_r.j - part1.j0) + 1)

@@ -744,13 +744,21 @@ def test_stage2_from_guessed_crosspoints_leaves_the_same_files(name, pair, bh, b
     runs = {}
     monkeypatch.delenv("MI355SW_STAGE2_SPECULATE", raising=False)   # (the whole file also passes with the variable set: every
     #                                                                    other test then walks stage 2 from guesses)
-    for mode in ("plain", "guessed", "guessed_batched", "recorded_peaks", "all_guesses_wrong"):
+    for mode in ("plain", "guessed", "guessed_batched", "recorded_peaks", "all_guesses_wrong", "cut_partitions"):
         work = str(tmp_path / mode)
         al = (Batched if mode == "guessed_batched" else SerialBlockAligner)(bh, bw)
         areas = {}
         # (round 6: guessing is the default and stage 1 records the row maxima as it writes; with the variable at 0 it does not,
         #  and a stage 2 that is asked to guess all the same reads them back from the rows)
         monkeypatch.setenv("MI355SW_STAGE2_SPECULATE", "1" if mode == "recorded_peaks" else "0")
+        if mode == "cut_partitions":
+            # guessed sweeps whose partitions END a few rows below where they give up (at C3 the cut lies 1.4 M rows down a
+            # 22 M-row partition; at these sizes only a shrunken slack makes it bite): a goal beyond the cut is a sweep given
+            # up, the walk makes that step itself -- the files do not change
+            import sys
+            stage2_mod = sys.modules["masa_cudalign_amd.stage2"]
+            monkeypatch.setattr(stage2_mod, "GUESS_CAP_SLACK", 8)
+            monkeypatch.setattr(stage2_mod, "GUESS_PARTITION_SLACK", 0)
         if mode == "all_guesses_wrong":
             real = sra.SpecialRowsPartition.row_peak
 
@@ -768,7 +776,7 @@ def test_stage2_from_guessed_crosspoints_leaves_the_same_files(name, pair, bh, b
         runs[mode] = (work, r2, r3)
     plain = runs["plain"]
     assert plain[1]["speculation"] is None
-    for mode in ("guessed", "guessed_batched", "recorded_peaks", "all_guesses_wrong"):
+    for mode in ("guessed", "guessed_batched", "recorded_peaks", "all_guesses_wrong", "cut_partitions"):
         work, r2, r3 = runs[mode]
         assert r2["crosspoints"] == plain[1]["crosspoints"] and r2["partitions"] == plain[1]["partitions"], mode
         assert r3["crosspoints"] == plain[2]["crosspoints"], mode
