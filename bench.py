@@ -683,7 +683,9 @@ def run_full_config(fc, pkg, torch, dist, make_dist, p2p_group, world, rank, loc
         s0, s1 = (pkg.seqgen.related_pair if related else pkg.seqgen.unrelated_pair)(m, n, cfg=fc["cfg"])
         mine["generate_s"] = time.time() - t0
         R = args.rows_per_lane or rows_per_lane_for_bands(m, lim[1] - lim[0], world, waves or 1024)
-        wait_s = float(os.environ.get("MI355SW_BENCH_EXTRA_WAIT_S", "900"))
+        # (how long a band's kernel waits for rows of its boundary column, and its driver for progress, before it gives up: band 7 of
+        #  C5 sees its first rows after the seed and seven first-strip sweeps, ~90 s; a neighbour that died is found out after this)
+        wait_s = float(os.environ.get("MI355SW_BENCH_EXTRA_WAIT_S", "600"))
         if comm == "p2p-attach":
             if rank == 0:
                 devs = [0] * world if rehearse else list(range(world))
